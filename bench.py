@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""Headline benchmark: volumes/sec of the CoMA-UNet training step at 128^3, batch 2 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = forward + GenerativeContrastiveLoss + backward + gradient all-reduce (N > 1) + fused
+AdamW on one batch of seeded synthetic volumes already resident in HBM.
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant convolution kernel family measured
+live with HIP events around each of its launches inside the timed region; `cpu_baseline` is the CPU
+oracle (this repo's restatement of the reference path -- the reference itself cannot be imported)
+timed on the host cores on a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_VALU_PEAK_TFLOPS = 157.3
+UNET_TFLOP_PER_VOLUME_128 = 2.340  # BASELINE.md section 2 (U-Net fwd+bwd, 128^3)
+
+
+def cpu_baseline(size, threads):
+    """One fwd+bwd step of the CPU oracle at `size`^3, batch 1 (bounded sample of the same workload)."""
+    from oracle.coma_oracle import build_reference_model
+    from oracle.criterions_oracle import build_reference_criterion, train_step_loss
+    from coma_unet_amd.synthetic import make_batch
+    torch.set_num_threads(threads)
+    S = (size,) * 3
+    torch.manual_seed(0)
+    m = build_reference_model(volume_shape=S, double_forward=False)
+    m.set_save_attn(None)
+    m.train(True)
+    b = make_batch(1, S, seed=0)
+    crit = build_reference_criterion()
+    t0 = time.perf_counter()
+    out = m(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])
+    train_step_loss(out, b["tau"], b["roi"], b["covars"], crit)[0].backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"CPU oracle (torch {torch.__version__}, fp32, single U-Net pass), 1 fwd+bwd step, "
+                      f"batch 1 at {size}^3, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=2, help="volumes per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import coma_unet_amd as cu
+    from coma_unet_amd import ops
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, make_optimizer
+    from coma_unet_amd.data_parallel import GradReducer, broadcast_module
+
+    S = (args.size,) * 3
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = cu.build_model(volume_shape=S, compute_dtype=dt, static_prompts=True).to(dev)
+    model.set_save_attn(None)
+    model.train(True)
+    if world > 1:
+        broadcast_module(model)
+    crit = cu.build_reference_criterion(dev)
+    opt = make_optimizer(model, 1e-3)
+    reducer = GradReducer(opt) if world > 1 else None
+    b = make_batch(args.batch, S, seed=1000 + rank)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    batch["roi_pred_dicts"] = model._priors(b["roi_pred_dicts"], args.batch, dev)   # (B,36,2) resident table
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step(model, crit, opt, batch, reducer)
+    ops.KernelTimer.enabled = not args.no_kernel_timer
+    ops.KernelTimer.records = []
+    sync_all()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last, _ = train_step(model, crit, opt, batch, reducer)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ops.KernelTimer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(last[0])
+
+    if rank == 0:
+        vols = args.batch * world * args.steps
+        value = vols / elapsed
+        summ = ops.KernelTimer.summary()
+        roof = None
+        kernels = {}
+        if summ:
+            for (kind, algo), (n, ms, fl) in sorted(summ.items()):
+                kernels[f"{kind}/{algo}"] = {"launches": n, "ms_total": round(ms, 3),
+                                             "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None}
+            (kind, algo), (n, ms, fl) = max(summ.items(), key=lambda kv: kv[1][1])
+            peak = MFMA_BF16_PEAK_TFLOPS if algo == "mfma" else FP32_VALU_PEAK_TFLOPS
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": f"{kind}/{algo}", "achieved": round(ach, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "launches": n, "avg_launch_ms": round(ms / n, 4),
+                    "step_tflops_all_convs": round(sum(v[2] for v in summ.values()) / args.steps / 1e12, 3)}
+        line = {
+            "metric": "volumes/sec (train fwd+bwd) at 128^3 bf16", "value": round(value, 4), "unit": "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"CoMA-UNet train step (fwd + RoiMSE/RnC loss + bwd + all-reduce + AdamW), "
+                                   f"{args.size}^3 volumes, batch {args.batch}/GPU, 6-dim covariates (BASELINE configs[3])",
+                       "global_batch": args.batch * world, "volume": list(S), "parallelism": f"dp{world}",
+                       "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 1)},
+            "loss": round(loss, 4),
+            "unet_tflops_per_s": round(value * UNET_TFLOP_PER_VOLUME_128 * (args.size / 128.0) ** 3, 2),
+            "roofline": roof, "conv_kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, 64)
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            line["cpu_baseline"] = cpu_baseline(args.size, threads)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+// C-ABI entry points that dispatch between kernel families, plus error reporting.
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void coma_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int coma_abi_version(void) { return COMA_ABI_VERSION; }
+extern "C" const char* coma_last_error(void) { return g_err; }
+
+// conv_direct.hip
+int conv_check(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
+int conv_direct_fwd(const coma_conv_desc* d, const coma_tensor* x, const float* wk, const float* bias,
+                    const coma_tensor* y, hipStream_t s);
+int conv_direct_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s);
+// norm.hip
+int colsum(const coma_tensor* x, int per_sample, float* out, void* ws, size_t ws_bytes, hipStream_t s);
+// conv_mfma.hip
+bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
+int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
+                  const coma_tensor* y, hipStream_t s);
+bool conv_mfma_wgrad_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
+size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
+int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws,
+                    size_t ws_bytes, hipStream_t s);
+
+extern "C" int coma_conv_pick_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  if (d->algo) return d->algo;
+  return conv_mfma_supported(d, x, y) ? 2 : 1;
+}
+
+extern "C" int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
+                             const float* bias, const coma_tensor* y, void* stream) {
+  if (int rc = conv_check(d, x, y)) return rc;
+  COMA_CHECK(wk, "conv_fwd: null weights");
+  hipStream_t s = (hipStream_t)stream;
+  const int algo = coma_conv_pick_algo(d, x, y);
+  if (algo == 2) {
+    COMA_CHECK(wk_dtype == COMA_BF16, "conv_fwd: MFMA path needs bf16 kernel-layout weights");
+    COMA_CHECK(conv_mfma_supported(d, x, y), "conv_fwd: shape not supported by the MFMA path (C=%d N=%d dtype=%d)",
+               x->C, y->C, x->dtype);
+    return conv_mfma_fwd(d, x, wk, bias, y, s);
+  }
+  COMA_CHECK(wk_dtype == COMA_F32, "conv_fwd: direct path needs fp32 kernel-layout weights");
+  return conv_direct_fwd(d, x, (const float*)wk, bias, y, s);
+}
+
+extern "C" int coma_conv_wgrad_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  if (d->algo) return d->algo;
+  return (x->dtype == COMA_BF16 && conv_mfma_wgrad_supported(d, x, dy)) ? 2 : 1;
+}
+
+extern "C" size_t coma_conv_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  size_t a = coma_norm_ws_bytes(dy);
+  size_t b = conv_mfma_wgrad_supported(d, x, dy) ? conv_mfma_wgrad_ws_bytes(d, x, dy) : 0;
+  return a > b ? a : b;
+}
+
+extern "C" int coma_conv_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk,
+                               float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = conv_check(d, x, dy)) return rc;
+  COMA_CHECK(dwk, "conv_wgrad: null dwk");
+  hipStream_t s = (hipStream_t)stream;
+  if (dbias) {
+    COMA_CHECK(ws && ws_bytes >= coma_norm_ws_bytes(dy), "conv_wgrad: workspace too small for the bias gradient");
+    if (int rc = colsum(dy, d->per_sample_w, dbias, ws, ws_bytes, s)) return rc;
+  }
+  const int algo = coma_conv_wgrad_algo(d, x, dy);
+  if (algo == 2) {
+    COMA_CHECK(conv_mfma_wgrad_supported(d, x, dy), "conv_wgrad: shape not supported by the MFMA path");
+    return conv_mfma_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
+  }
+  return conv_direct_wgrad(d, x, dy, dwk, s);
+}

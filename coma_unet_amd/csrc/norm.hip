@@ -1,0 +1,378 @@
+// BatchNorm3d (training statistics) / InstanceNorm3d + fused activation, forward and
+// backward, for channels-last volumes.  Replaces the ATen norm + activation dispatches
+// behind MONAI's ADN blocks ("N","A": BN+ReLU in ConvBlock/UpConv, IN+PReLU in the merge
+// convs, IN+LeakyReLU in StackedFusionConvLayers attn_unet_data_parallel.py:480-501) and
+// the bare BatchNorm3d layers of the attention gate (:141-144).  HBM-bound: one read for
+// the statistics, one read + one write for the apply; statistics are accumulated in fp64
+// and reduced in a fixed order (bitwise reproducible).
+#include "common.h"
+
+struct RowsP {            // a [G][R rows][C] view of a coma_tensor
+  const void* x; int64_t ld, sb; int64_t V; int B; int C;
+  int G;                  // groups: 1 (batch) or B (instance)
+  int64_t R;              // rows per group: B*V or V
+  int cv, cvp, ry;        // channel vectors, padded to pow2, rows per block step
+  int64_t ch;             // rows per chunk
+  int nchunks;
+};
+
+static RowsP make_rows(const coma_tensor* x, int mode, int vec) {
+  RowsP p;
+  p.x = x->data; p.ld = x->ld; p.sb = x->sb; p.V = t_vox(x); p.B = x->B; p.C = x->C;
+  p.G = mode == COMA_NORM_INSTANCE ? x->B : 1;
+  p.R = mode == COMA_NORM_INSTANCE ? p.V : p.V * x->B;
+  p.cv = x->C / vec;
+  int cvp = 1; while (cvp < p.cv) cvp <<= 1;
+  if (cvp > 256) cvp = 256;
+  p.cvp = cvp; p.ry = 256 / cvp;
+  int64_t nch = (p.R + (int64_t)p.ry * 16 - 1) / ((int64_t)p.ry * 16);
+  const int64_t cap = 1024 / p.G > 0 ? 1024 / p.G : 1;
+  if (nch > cap) nch = cap;
+  if (nch < 1) nch = 1;
+  p.nchunks = (int)nch;
+  p.ch = (p.R + nch - 1) / nch;
+  return p;
+}
+
+__device__ __forceinline__ int64_t row_off(const RowsP& p, int g, int64_t r) {
+  // group g, row r -> element offset of channel 0
+  if (p.G == 1) { const int64_t b = r / p.V, v = r - b * p.V; return b * p.sb + v * p.ld; }
+  return (int64_t)g * p.sb + r * p.ld;
+}
+
+// partial[(chunk*G + g)*C + c] = {sum, sumsq} over the chunk's rows
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double2* partial) {
+  __shared__ double sh[256][2 * VEC];
+  const int tid = threadIdx.x, tx = tid % p.cvp, ty = tid / p.cvp;
+  const int g = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * p.ch;
+  const int64_t r1 = r0 + p.ch < p.R ? r0 + p.ch : p.R;
+  double s[VEC], q[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s[j] = 0.0; q[j] = 0.0; }
+  if (tx < p.cv) {
+    const T* base = reinterpret_cast<const T*>(p.x);
+    for (int64_t r = r0 + ty; r < r1; r += p.ry) {
+      float v[VEC];
+      vec_io<T, VEC>::load(base + row_off(p, g, r) + tx * VEC, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s[j] += (double)v[j]; q[j] += (double)v[j] * (double)v[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sh[tid][2 * j] = s[j]; sh[tid][2 * j + 1] = q[j]; }
+  __syncthreads();
+  if (ty == 0 && tx < p.cv) {
+    for (int y = 1; y < p.ry; ++y)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s[j] += sh[y * p.cvp + tx][2 * j]; q[j] += sh[y * p.cvp + tx][2 * j + 1]; }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      partial[((int64_t)blockIdx.x * p.G + g) * p.C + tx * VEC + j] = make_double2(s[j], q[j]);
+  }
+}
+
+__global__ void stats_finalize_k(const double2* partial, int nchunks, int G, int C, int64_t R, float eps,
+                                 float* mean, float* rstd, float* rmean, float* rvar, float momentum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < nchunks; ++k) { const double2 v = partial[(int64_t)k * G * C + i]; s += v.x; q += v.y; }
+  const double m = s / (double)R;
+  double var = q / (double)R - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean && G == 1) {
+    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    rmean[i] = (1.f - momentum) * rmean[i] + momentum * (float)m;
+    rvar[i] = (1.f - momentum) * rvar[i] + momentum * (float)unb;
+  }
+}
+
+struct ApplyP {
+  const void* x; int64_t ldx, sbx;
+  void* y; int64_t ldy, sby;
+  const void* dy; int64_t lddy, sbdy;
+  int64_t V; int B, C, cv; int inst;
+  const float *mean, *rstd, *gamma, *beta, *slope;
+  int act;
+};
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void norm_act_fwd_k(ApplyP p) {
+  const int b = blockIdx.y;
+  const int64_t total = p.V * p.cv;
+  const float a = p.slope ? *p.slope : 0.25f;
+  const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.sbx;
+  T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * p.sby;
+  const int g = p.inst ? b : 0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t v = e / p.cv; const int c0 = (int)(e - v * p.cv) * VEC;
+    float xv[VEC], yv[VEC];
+    vec_io<T, VEC>::load(xb + v * p.ldx + c0, xv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      float z = (xv[j] - p.mean[g * p.C + c]) * p.rstd[g * p.C + c];
+      if (p.gamma) z = z * p.gamma[c] + p.beta[c];
+      yv[j] = act_fwd(p.act, z, a);
+    }
+    vec_io<T, VEC>::store(yb + v * p.ldy + c0, yv);
+  }
+}
+
+// backward pass 1: per (g,c) partial {sum dz, sum dz*xhat, sum dy*dact/dslope}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* dyp, int64_t lddy, int64_t sbdy,
+                                                          const float* mean, const float* rstd, const float* gamma,
+                                                          const float* beta, int act, const float* slope,
+                                                          double* partial /* [chunk][G][C][3] */) {
+  __shared__ double sh[256][3 * VEC];
+  const int tid = threadIdx.x, tx = tid % p.cvp, ty = tid / p.cvp;
+  const int g = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * p.ch;
+  const int64_t r1 = r0 + p.ch < p.R ? r0 + p.ch : p.R;
+  const float a = slope ? *slope : 0.25f;
+  double s1[VEC], s2[VEC], s3[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s1[j] = s2[j] = s3[j] = 0.0; }
+  if (tx < p.cv) {
+    const T* xb = reinterpret_cast<const T*>(p.x);
+    const T* dyb = reinterpret_cast<const T*>(dyp);
+    RowsP pd = p; pd.ld = lddy; pd.sb = sbdy;
+    float mu[VEC], rs[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = tx * VEC + j;
+      mu[j] = mean[g * p.C + c]; rs[j] = rstd[g * p.C + c];
+      ga[j] = gamma ? gamma[c] : 1.f; be[j] = gamma ? beta[c] : 0.f;
+    }
+    for (int64_t r = r0 + ty; r < r1; r += p.ry) {
+      float xv[VEC], dv[VEC];
+      vec_io<T, VEC>::load(xb + row_off(p, g, r) + tx * VEC, xv);
+      vec_io<T, VEC>::load(dyb + row_off(pd, g, r) + tx * VEC, dv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float xh = (xv[j] - mu[j]) * rs[j];
+        const float z = xh * ga[j] + be[j];
+        float ds; const float da = act_bwd(act, z, a, &ds);
+        const float dz = dv[j] * da;
+        s1[j] += (double)dz; s2[j] += (double)dz * (double)xh; s3[j] += (double)dv[j] * (double)ds;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sh[tid][3 * j] = s1[j]; sh[tid][3 * j + 1] = s2[j]; sh[tid][3 * j + 2] = s3[j]; }
+  __syncthreads();
+  if (ty == 0 && tx < p.cv) {
+    for (int y = 1; y < p.ry; ++y)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        s1[j] += sh[y * p.cvp + tx][3 * j]; s2[j] += sh[y * p.cvp + tx][3 * j + 1]; s3[j] += sh[y * p.cvp + tx][3 * j + 2];
+      }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      double* o = partial + (((int64_t)blockIdx.x * p.G + g) * p.C + tx * VEC + j) * 3;
+      o[0] = s1[j]; o[1] = s2[j]; o[2] = s3[j];
+    }
+  }
+}
+
+// reduce chunks -> sums[G][C][2] (fp32: mean dz, mean dz*xhat), dgamma/dbeta[C], dslope
+__global__ void norm_bwd_finalize_k(const double* partial, int nchunks, int G, int C, int64_t R, float* sums,
+                                    float* dgamma, float* dbeta, float* dslope) {
+  __shared__ double ssl[256];
+  double sl = 0.0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double dg = 0.0, db = 0.0;
+    for (int g = 0; g < G; ++g) {
+      double a = 0.0, b = 0.0, s = 0.0;
+      for (int k = 0; k < nchunks; ++k) {
+        const double* v = partial + (((int64_t)k * G + g) * C + c) * 3;
+        a += v[0]; b += v[1]; s += v[2];
+      }
+      sums[(g * C + c) * 2] = (float)(a / (double)R);
+      sums[(g * C + c) * 2 + 1] = (float)(b / (double)R);
+      db += a; dg += b; sl += s;
+    }
+    if (dgamma) dgamma[c] = (float)dg;
+    if (dbeta) dbeta[c] = (float)db;
+  }
+  ssl[threadIdx.x] = sl;
+  __syncthreads();
+  if (threadIdx.x == 0 && dslope) {
+    double t = 0.0;
+    for (int i = 0; i < (int)blockDim.x; ++i) t += ssl[i];
+    *dslope = (float)t;
+  }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p, const float* sums) {
+  const int b = blockIdx.y;
+  const int64_t total = p.V * p.cv;
+  const float a = p.slope ? *p.slope : 0.25f;
+  const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.sbx;
+  const T* dyb = reinterpret_cast<const T*>(p.dy) + (int64_t)b * p.sbdy;
+  T* ob = reinterpret_cast<T*>(p.y) + (int64_t)b * p.sby;
+  const int g = p.inst ? b : 0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t v = e / p.cv; const int c0 = (int)(e - v * p.cv) * VEC;
+    float xv[VEC], dv[VEC], ov[VEC];
+    vec_io<T, VEC>::load(xb + v * p.ldx + c0, xv);
+    vec_io<T, VEC>::load(dyb + v * p.lddy + c0, dv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      const float rs = p.rstd[g * p.C + c];
+      const float xh = (xv[j] - p.mean[g * p.C + c]) * rs;
+      const float ga = p.gamma ? p.gamma[c] : 1.f;
+      const float z = p.gamma ? xh * ga + p.beta[c] : xh;
+      float ds; const float da = act_bwd(p.act, z, a, &ds);
+      const float dz = dv[j] * da;
+      ov[j] = rs * ga * (dz - sums[(g * p.C + c) * 2] - xh * sums[(g * p.C + c) * 2 + 1]);
+    }
+    vec_io<T, VEC>::store(ob + v * p.ldy + c0, ov);
+  }
+}
+
+// column sums of a [B][V][C] tensor -> fp32 out[B or 1][C]  (conv bias gradient, spatial mean)
+__global__ void colsum_finalize_k(const double2* partial, int nchunks, int G, int C, double scale, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  double s = 0.0;
+  for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * G * C + i].x;
+  out[i] = (float)(s * scale);
+}
+
+static int pick_vec(const coma_tensor* x) { return t_vec(x, 4) >= 4 ? 4 : 1; }
+
+extern "C" size_t coma_norm_ws_bytes(const coma_tensor* x) {
+  // partials: <= 1024 (chunk,group) pairs x C x 3 doubles, + sums [B][C][2] floats
+  return (size_t)1024 * x->C * 3 * sizeof(double) + (size_t)x->B * x->C * 2 * sizeof(float) + 256;
+}
+
+template <typename T>
+static void launch_partial(const RowsP& p, int vec, double2* partial, hipStream_t s) {
+  dim3 grid(p.nchunks, p.G);
+  if (vec == 4) hipLaunchKernelGGL((stats_partial_k<T, 4>), grid, dim3(256), 0, s, p, partial);
+  else hipLaunchKernelGGL((stats_partial_k<T, 1>), grid, dim3(256), 0, s, p, partial);
+}
+
+static int run_partial(const coma_tensor* x, int mode, RowsP& p, void* ws, size_t ws_bytes, hipStream_t s) {
+  COMA_CHECK(x && x->data && ws, "norm: null argument");
+  COMA_CHECK(ws_bytes >= coma_norm_ws_bytes(x), "norm: workspace too small (%zu < %zu)", ws_bytes, coma_norm_ws_bytes(x));
+  const int vec = pick_vec(x);
+  p = make_rows(x, mode, vec);
+  COMA_CHECK(p.cv <= 256, "norm: C=%d too large", x->C);
+  if (x->dtype == COMA_F32) launch_partial<float>(p, vec, (double2*)ws, s);
+  else launch_partial<bf16_t>(p, vec, (double2*)ws, s);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coma_norm_stats(const coma_tensor* x, int32_t mode, float eps, float* mean, float* rstd,
+                               float* running_mean, float* running_var, float momentum, void* ws,
+                               size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  RowsP p;
+  if (int rc = run_partial(x, mode, p, ws, ws_bytes, s)) return rc;
+  const int n = p.G * p.C;
+  hipLaunchKernelGGL(stats_finalize_k, dim3((n + 127) / 128), dim3(128), 0, s, (const double2*)ws, p.nchunks, p.G,
+                     p.C, p.R, eps, mean, rstd, running_mean, running_var, momentum);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coma_spatial_mean(const coma_tensor* x, float* out, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  RowsP p;
+  if (int rc = run_partial(x, COMA_NORM_INSTANCE, p, ws, ws_bytes, s)) return rc;
+  const int n = p.G * p.C;
+  hipLaunchKernelGGL(colsum_finalize_k, dim3((n + 127) / 128), dim3(128), 0, s, (const double2*)ws, p.nchunks, p.G,
+                     p.C, 1.0 / (double)p.R, out);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// used by coma_conv_wgrad for the bias gradient: out[B or 1][C] = sum over voxels (and batch)
+int colsum(const coma_tensor* x, int per_sample, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+  RowsP p;
+  if (int rc = run_partial(x, per_sample ? COMA_NORM_INSTANCE : COMA_NORM_BATCH, p, ws, ws_bytes, s)) return rc;
+  const int n = p.G * p.C;
+  hipLaunchKernelGGL(colsum_finalize_k, dim3((n + 127) / 128), dim3(128), 0, s, (const double2*)ws, p.nchunks, p.G,
+                     p.C, 1.0, out);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
+static ApplyP make_apply(const coma_tensor* x, const coma_tensor* y, int mode, int vec) {
+  ApplyP p;
+  p.x = x->data; p.ldx = x->ld; p.sbx = x->sb;
+  p.y = y->data; p.ldy = y->ld; p.sby = y->sb;
+  p.dy = nullptr; p.lddy = 0; p.sbdy = 0;
+  p.V = t_vox(x); p.B = x->B; p.C = x->C; p.cv = x->C / vec; p.inst = mode == COMA_NORM_INSTANCE;
+  return p;
+}
+
+static unsigned ew_blocks(int64_t total) {
+  int64_t nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  return (unsigned)(nb < 1 ? 1 : nb);
+}
+
+extern "C" int coma_norm_act_fwd(const coma_tensor* x, int32_t mode, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, int32_t act, const float* slope,
+                                 const coma_tensor* y, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  COMA_CHECK(x && y && x->data && y->data && mean && rstd, "norm_act_fwd: null argument");
+  COMA_CHECK(t_same_grid(x, y) && x->C == y->C && x->dtype == y->dtype, "norm_act_fwd: shape/dtype mismatch");
+  const int vec = (pick_vec(x) == 4 && pick_vec(y) == 4) ? 4 : 1;
+  ApplyP p = make_apply(x, y, mode, vec);
+  p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.slope = slope; p.act = act;
+  dim3 grid(ew_blocks(p.V * p.cv), x->B);
+#define L(T, V) hipLaunchKernelGGL((norm_act_fwd_k<T, V>), grid, dim3(256), 0, s, p)
+  if (x->dtype == COMA_F32) { if (vec == 4) L(float, 4); else L(float, 1); }
+  else { if (vec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
+#undef L
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, int32_t mode, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, int32_t act,
+                                 const float* slope, const coma_tensor* dx, float* dgamma, float* dbeta,
+                                 float* dslope, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  COMA_CHECK(x && dy && dx && x->data && dy->data && dx->data && mean && rstd && ws, "norm_act_bwd: null argument");
+  COMA_CHECK(t_same_grid(x, dy) && t_same_grid(x, dx) && x->C == dy->C && x->C == dx->C, "norm_act_bwd: shape mismatch");
+  COMA_CHECK(x->dtype == dy->dtype && x->dtype == dx->dtype, "norm_act_bwd: dtype mismatch");
+  COMA_CHECK(ws_bytes >= coma_norm_ws_bytes(x), "norm_act_bwd: workspace too small");
+  const int vec = (pick_vec(x) == 4 && pick_vec(dy) == 4 && pick_vec(dx) == 4) ? 4 : 1;
+  RowsP rp = make_rows(x, mode, vec);
+  COMA_CHECK(rp.cv <= 256, "norm: C=%d too large", x->C);
+  double* partial = (double*)ws;
+  float* sums = (float*)((char*)ws + (size_t)1024 * x->C * 3 * sizeof(double));
+  dim3 pg(rp.nchunks, rp.G);
+#define L(T, V) hipLaunchKernelGGL((norm_bwd_partial_k<T, V>), pg, dim3(256), 0, s, rp, dy->data, dy->ld, dy->sb, \
+                                   mean, rstd, gamma, beta, act, slope, partial)
+  if (x->dtype == COMA_F32) { if (vec == 4) L(float, 4); else L(float, 1); }
+  else { if (vec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
+#undef L
+  COMA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_bwd_finalize_k, dim3(1), dim3(256), 0, s, partial, rp.nchunks, rp.G, rp.C, rp.R, sums,
+                     dgamma, dbeta, dslope);
+  COMA_LAUNCH_CHECK();
+  ApplyP p = make_apply(x, dx, mode, vec);
+  p.dy = dy->data; p.lddy = dy->ld; p.sbdy = dy->sb;
+  p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.slope = slope; p.act = act;
+  dim3 grid(ew_blocks(p.V * p.cv), x->B);
+#define L(T, V) hipLaunchKernelGGL((norm_act_bwd_apply_k<T, V>), grid, dim3(256), 0, s, p, sums)
+  if (x->dtype == COMA_F32) { if (vec == 4) L(float, 4); else L(float, 1); }
+  else { if (vec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
+#undef L
+  COMA_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,127 @@
+"""Explicit per-GPU replicas + gradient all-reduce over RCCL (replaces the
+``torch.nn.DataParallel`` the reference imports but never applies,
+attn_unet_data_parallel.py:32,1554; validation.py:268-269 -- SURVEY.md F4).
+
+One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).  Every rank
+holds a full replica with identical initial weights (broadcast once), runs forward /
+backward on its own samples, and the flat gradient buffer of ``FusedAdamW`` is SUM-reduced
+in contiguous buckets.  SUM, not mean: the reference reduces the per-sample loss vector with
+``torch.sum`` (criterions.py:560), so a global batch's gradient is the sum of the replicas'.
+
+Overlap: each bucket's all-reduce is issued from a post-accumulate-grad hook as soon as the
+last gradient of that bucket has been produced by backward; RCCL runs it on the process
+group's own HIP stream while the compute stream continues with the rest of backward, and
+``finish()`` makes the compute stream wait before the optimizer reads the buffer.
+
+BatchNorm statistics and running buffers stay per replica (what an unsynchronised
+DataParallel would have done; ``SyncBatchNorm`` is imported upstream but never used).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def broadcast_module(module, src=0, group=None):
+    """Identical initial replicas: parameters and buffers of rank `src` to everyone."""
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+
+
+class GradReducer:
+    def __init__(self, optimizer, bucket_bytes=64 << 20, group=None, overlap=True):
+        self.opt = optimizer
+        self.group = group
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.overlap = overlap
+        self._hooks = []
+        self._works = []
+        self._buckets = None      # list of [start, end, n_params_pending, n_params_total]
+        self._p2b = {}
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    # -- first step: no flat layout yet -> one flattened all-reduce of whatever has a gradient
+    def _reduce_unbuilt(self, params):
+        gs = [p.grad for p in params if p.grad is not None]
+        if not gs:
+            return
+        flat = torch.cat([g.reshape(-1).float() for g in gs])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for g in gs:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+    def _install(self):
+        opt = self.opt
+        n = opt.flat_g.numel()
+        bounds, start = [], 0
+        # cut the flat buffer at parameter boundaries into ~bucket_elems pieces
+        cur = 0
+        for p in opt._flat_params:
+            off, k = opt._offsets[id(p)]
+            if off + k - start >= self.bucket_elems:
+                bounds.append((start, off + k))
+                start = off + k
+        if start < n:
+            bounds.append((start, n))
+        self._buckets = [[s, e, 0, 0] for s, e in bounds]
+        bi = 0
+        for p in opt._flat_params:
+            off, k = opt._offsets[id(p)]
+            while off >= self._buckets[bi][1]:
+                bi += 1
+            self._p2b[id(p)] = bi
+            self._buckets[bi][3] += 1
+            if self.overlap:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self.reset()
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            b = self._buckets[bi]
+            b[2] -= 1
+            if b[2] == 0:
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        s, e = self._buckets[bi][0], self._buckets[bi][1]
+        w = dist.all_reduce(self.opt.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(w)
+        self._buckets[bi][2] = -1   # launched
+
+    def reset(self):
+        """Call before each backward."""
+        self._works = []
+        if self._buckets is not None:
+            for b in self._buckets:
+                b[2] = b[3]
+
+    def finish(self):
+        """Call after backward, before optimizer.step()."""
+        if self.world == 1:
+            return
+        opt = self.opt
+        params = opt.param_groups[0]["params"]
+        if not opt.built:
+            self._reduce_unbuilt(params)
+            return
+        if self._buckets is None:
+            # layout was built by the previous step(); grads of THIS backward went straight into flat_g
+            self._install()
+            for bi in range(len(self._buckets)):
+                self._launch(bi)
+        else:
+            for bi, b in enumerate(self._buckets):
+                if b[2] != -1:          # a parameter's hook did not fire (or overlap is off)
+                    self._launch(bi)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        # tensors outside the flat buffer (the two selectable prompts)
+        rest = [p for p in params if id(p) not in opt._flat_ids and p.grad is not None]
+        for p in rest:
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)

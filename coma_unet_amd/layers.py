@@ -1,0 +1,186 @@
+"""Building blocks of the MI355X CoMA-UNet: same module tree / state_dict keys as the
+reference stack (MONAI ``Convolution``/``ADN``/``attentionunet`` blocks + the reference's
+``CondConv`` module), forward and backward executed by the HIP library.
+
+``nn.Conv3d`` / ``nn.BatchNorm3d`` / ``nn.PReLU`` / ``nn.Linear`` instances below are used
+as PARAMETER HOLDERS only (identical initialisation and state_dict keys to the reference
+stack); their ``forward`` is never called.  All tensors inside the model are channels-last
+``(B, D, H, W, C)``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+from .ops import Out
+
+
+class Config:
+    """Shared by every layer of one model."""
+
+    def __init__(self, compute_dtype=torch.float32, conv_algo=0, bn_updates_per_forward=1):
+        self.compute_dtype = compute_dtype
+        self.conv_algo = conv_algo            # 0 auto, 1 direct VALU fp32, 2 MFMA bf16
+        self.bn_updates_per_forward = bn_updates_per_forward
+
+
+def _wdtype(algo):
+    return torch.bfloat16 if algo == 2 else torch.float32
+
+
+_ACTS = {None: L.ACT_NONE, "relu": L.ACT_RELU, "prelu": L.ACT_PRELU, "leakyrelu": L.ACT_LEAKY,
+         "sigmoid": L.ACT_SIGMOID, "prelu_relu": L.ACT_PRELU_RELU}
+
+
+class ADN(nn.Module):
+    """MONAI ADN, ordering "NDA" with p=0 dropout: norm (``N``) then activation (``A``)."""
+
+    def __init__(self, cfg, channels, act="prelu", norm="instance"):
+        super().__init__()
+        self.cfg = cfg
+        self.mode = L.NORM_BATCH if norm == "batch" else L.NORM_INSTANCE
+        self.act_name = act
+        if norm == "batch":
+            self.N = nn.BatchNorm3d(channels)
+        else:
+            self.N = nn.InstanceNorm3d(channels)
+        if act in ("prelu", "prelu_relu"):
+            self.A = nn.PReLU()
+        elif act == "relu":
+            self.A = nn.ReLU()
+        elif act == "leakyrelu":
+            self.A = nn.LeakyReLU(0.01, inplace=True)
+
+    def forward(self, x, out=None):
+        return norm_act(self.cfg, x, self.N if self.mode == L.NORM_BATCH else None, self.mode,
+                        _ACTS[self.act_name], self.A.weight if self.act_name in ("prelu", "prelu_relu") else None,
+                        self.training, out)
+
+
+def norm_act(cfg, x, bn, mode, act, slope, training, out=None):
+    gamma = beta = rmean = rvar = None
+    momentum, eps = 0.1, 1e-5
+    if bn is not None:
+        gamma, beta, rmean, rvar = bn.weight, bn.bias, bn.running_mean, bn.running_var
+        eps = bn.eps
+        k = cfg.bn_updates_per_forward
+        momentum = 1.0 - (1.0 - bn.momentum) ** k     # k identical updates folded into one
+        if training:
+            bn.num_batches_tracked += k
+    return ops.NormAct.apply(x, gamma, beta, slope, rmean, rvar, mode, act, momentum, eps, training,
+                             Out(out) if out is not None else None)
+
+
+def conv_plain(cfg, x, conv: nn.Module, ksize, stride, transposed, out=None):
+    """nn.Conv3d / nn.ConvTranspose3d semantics with shared weights."""
+    n_out = conv.weight.shape[1] if transposed else conv.weight.shape[0]
+    a_f, a_d = ops.pick_algo(x.shape, x.dtype, n_out, ksize, stride, transposed, False, x.device, cfg.conv_algo)
+    need_dx = x.requires_grad
+    wk_f, wk_d = ops.PrepWeights.apply(conv.weight, None, transposed, _wdtype(a_f), _wdtype(a_d) if need_dx else None)
+    return ops.Conv.apply(x, wk_f, wk_d, conv.bias, ksize, stride, transposed, False, cfg.conv_algo,
+                          Out(out) if out is not None else None)
+
+
+class Convolution(nn.Module):
+    """MONAI ``Convolution`` (3-D): conv (+ ADN)."""
+
+    def __init__(self, cfg, in_channels, out_channels, strides=1, kernel_size=3, act="prelu", norm="instance",
+                 conv_only=False, is_transposed=False):
+        super().__init__()
+        self.cfg, self.k, self.s, self.transposed = cfg, kernel_size, strides, is_transposed
+        p = (kernel_size - 1) // 2
+        if is_transposed:
+            self.conv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride=strides, padding=p,
+                                           output_padding=strides - 1)
+        else:
+            self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=strides, padding=p)
+        if not conv_only:
+            self.adn = ADN(cfg, out_channels, act=act, norm=norm)
+        else:
+            self.adn = None
+
+    def forward(self, x, out=None):
+        if self.adn is None:
+            return conv_plain(self.cfg, x, self.conv, self.k, self.s, self.transposed, out)
+        y = conv_plain(self.cfg, x, self.conv, self.k, self.s, self.transposed)
+        return self.adn(y, out)
+
+
+class MonaiConvBlock(nn.Module):
+    """MONAI ``attentionunet.ConvBlock`` (used by ProjectionHead with kernel_size=1)."""
+
+    def __init__(self, cfg, in_channels, out_channels, kernel_size=3, strides=1):
+        super().__init__()
+        self.conv = nn.Sequential(
+            Convolution(cfg, in_channels, out_channels, strides=strides, kernel_size=kernel_size, act="relu", norm="batch"),
+            Convolution(cfg, out_channels, out_channels, strides=1, kernel_size=kernel_size, act="relu", norm="batch"))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+# ---------------------------------------------------------------------------------------
+# CondConv (spec: DESIGN.md; the upstream module is missing, attn_unet_data_parallel.py:28)
+# ---------------------------------------------------------------------------------------
+class CondConv3d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride, num_experts, num_covars, is_transposed=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.is_transposed = kernel_size, stride, is_transposed
+        self.num_experts, self.num_covars = num_experts, num_covars
+        k = kernel_size
+        shape = (in_channels, out_channels, k, k, k) if is_transposed else (out_channels, in_channels, k, k, k)
+        self.weight = nn.Parameter(torch.empty(num_experts, *shape))
+        self.bias = nn.Parameter(torch.empty(num_experts, out_channels))
+        self.routing = nn.Linear(num_covars, num_experts)
+        for e in range(num_experts):
+            nn.init.kaiming_uniform_(self.weight[e], a=5 ** 0.5)
+        fan_in = self.weight[0].size(1) * k ** 3
+        nn.init.uniform_(self.bias, -1.0 / fan_in ** 0.5, 1.0 / fan_in ** 0.5)
+
+
+def conv_cond(cfg, x, cc: CondConv3d, covariate, out=None):
+    B = x.shape[0]
+    cov = covariate.reshape(B, -1).to(device=x.device, dtype=torch.float32)
+    assert cov.shape[1] == cc.num_covars, (cov.shape, cc.num_covars)
+    # routing: a (B x num_covars) @ (num_covars x E) product + sigmoid -- host-side glue on <= 64 numbers
+    r = torch.sigmoid(F.linear(cov, cc.routing.weight, cc.routing.bias))
+    bias = r @ cc.bias                                         # (B, Cout), same glue
+    a_f, a_d = ops.pick_algo(x.shape, x.dtype, cc.out_channels, cc.kernel_size, cc.stride, cc.is_transposed, True,
+                             x.device, cfg.conv_algo)
+    need_dx = x.requires_grad
+    wk_f, wk_d = ops.PrepWeights.apply(cc.weight, r, cc.is_transposed, _wdtype(a_f), _wdtype(a_d) if need_dx else None)
+    return ops.Conv.apply(x, wk_f, wk_d, bias, cc.kernel_size, cc.stride, cc.is_transposed, True, cfg.conv_algo,
+                          Out(out) if out is not None else None)
+
+
+class CondConvolution(nn.Module):
+    def __init__(self, cfg, in_channels, out_channels, strides=1, kernel_size=3, act="prelu", norm="instance",
+                 conv_only=False, is_transposed=False, num_experts=8, num_covars=5):
+        super().__init__()
+        self.cfg = cfg
+        self.conv = CondConv3d(in_channels, out_channels, kernel_size, strides, num_experts, num_covars, is_transposed)
+        self.adn = None if conv_only else ADN(cfg, out_channels, act=act, norm=norm)
+
+    def forward(self, x, covariate=None, out=None):
+        if self.adn is None:
+            return conv_cond(self.cfg, x, self.conv, covariate, out)
+        return self.adn(conv_cond(self.cfg, x, self.conv, covariate), out)
+
+
+class CondConvBlock(nn.Module):
+    def __init__(self, cfg, in_channels, out_channels, kernel_size=3, strides=1, num_covars=5, num_experts=8):
+        super().__init__()
+        self.conv = nn.ModuleList([
+            CondConvolution(cfg, in_channels, out_channels, strides=strides, kernel_size=kernel_size, act="relu",
+                            norm="batch", num_experts=num_experts, num_covars=num_covars),
+            CondConvolution(cfg, out_channels, out_channels, strides=1, kernel_size=kernel_size, act="relu",
+                            norm="batch", num_experts=num_experts, num_covars=num_covars)])
+
+    def forward(self, x, covariate=None):
+        for c in self.conv:
+            x = c(x, covariate)
+        return x

@@ -1,0 +1,425 @@
+"""torch.autograd.Function wrappers over the C ABI (include/coma_unet.h).
+
+Internal activation layout is channels-last (B, D, H, W, C); a tensor may be a channel
+slice of a wider buffer (that is how the reference's torch.cat calls,
+attn_unet_data_parallel.py:229,651,654, are made copy-free).  Every Function calls the HIP
+library on the current stream; none of them has a CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from ._lib import lib, ct, ptr, check, workspace
+
+
+class Out:
+    """Side-channel holder for a pre-allocated destination view (not an autograd input)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+class KernelTimer:
+    """Optional HIP-event bracket around every convolution launch (bench.py's live roofline leg).
+    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
+    enabled = False
+    records = []   # (kind, algo, flops, ev_start, ev_end)
+
+    @classmethod
+    def run(cls, kind, algo, flops, fn):
+        if not cls.enabled:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        cls.records.append((kind, algo, flops, e0, e1))
+        return r
+
+    @classmethod
+    def summary(cls):
+        """{(kind, algo): (launches, total_ms, total_flops)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for kind, algo, flops, e0, e1 in cls.records:
+            n, ms, fl = out.get((kind, algo), (0, 0.0, 0.0))
+            out[(kind, algo)] = (n + 1, ms + e0.elapsed_time(e1), fl + flops)
+        return out
+
+
+def conv_flops(x_shape, y_shape, ksize, stride):
+    """2 * MACs of one gather launch: every (coarse-grid voxel, tap, c, n) combination once."""
+    vx = x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3]
+    vy = y_shape[0] * y_shape[1] * y_shape[2] * y_shape[3]
+    return 2.0 * min(vx, vy) * (ksize ** 3) * x_shape[4] * y_shape[4]
+
+
+def _new(shape, dtype, device):
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def _f32(n, device):
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+# --------------------------------------------------------------------------------------
+# weights: CondConv expert mixing + kernel-layout cast
+# --------------------------------------------------------------------------------------
+class PrepWeights(Function):
+    """master ([E,] A, B, k,k,k) fp32 (+ routing r (Bw, E)) -> (wk_fwd, wk_dgrad).
+
+    wk_fwd [Bw, taps, Cout, Cin] feeds the forward gather, wk_dgrad [Bw, taps, Cin, Cout]
+    the data-gradient gather; dtypes are chosen by the conv algo (fp32 direct / bf16 MFMA).
+    """
+
+    @staticmethod
+    def forward(ctx, master, r, transposed, fwd_dtype, dgrad_dtype):
+        has_e = r is not None
+        m = master if has_e else master.unsqueeze(0)
+        assert m.is_contiguous() and m.dtype == torch.float32
+        E, A, Bc = m.shape[0], m.shape[1], m.shape[2]
+        taps = m.shape[3] * m.shape[4] * m.shape[5]
+        cout, cin = (Bc, A) if transposed else (A, Bc)
+        se = A * Bc * taps
+        if transposed:      # master [ci][co][tap]
+            sn_f, sc_f = taps, cout * taps
+        else:               # master [co][ci][tap]
+            sn_f, sc_f = cin * taps, taps
+        Bw = r.shape[0] if has_e else 1
+        rr = r.contiguous().float() if has_e else None
+        dev = master.device
+        wk_f = _new((Bw, taps, cout, cin), fwd_dtype, dev)
+        check(lib.coma_weight_prep(ptr(m), ptr(rr), E, Bw, cout, cin, taps, se, sn_f, sc_f, ptr(wk_f),
+                                   L.dtype_code(fwd_dtype), L.stream()), "coma_weight_prep")
+        wk_d = None
+        if dgrad_dtype is not None:
+            wk_d = _new((Bw, taps, cin, cout), dgrad_dtype, dev)
+            check(lib.coma_weight_prep(ptr(m), ptr(rr), E, Bw, cin, cout, taps, se, sc_f, sn_f, ptr(wk_d),
+                                       L.dtype_code(dgrad_dtype), L.stream()), "coma_weight_prep")
+            ctx.mark_non_differentiable(wk_d)
+        ctx.save_for_backward(master, rr)
+        ctx.meta = (has_e, E, Bw, cout, cin, taps, se, sn_f, sc_f)
+        return wk_f, wk_d
+
+    @staticmethod
+    def backward(ctx, dwk_f, _dwk_d):
+        master, rr = ctx.saved_tensors
+        has_e, E, Bw, cout, cin, taps, se, sn_f, sc_f = ctx.meta
+        dwk = dwk_f.contiguous().float()
+        dmaster = torch.empty_like(master)
+        dr = _f32((Bw, E), master.device) if has_e else None
+        check(lib.coma_weight_prep_bwd(ptr(dwk), ptr(master), ptr(rr), E, Bw, cout, cin, taps, se, sn_f, sc_f,
+                                       ptr(dmaster), ptr(dr), L.stream()), "coma_weight_prep_bwd")
+        return dmaster, dr, None, None, None
+
+
+# --------------------------------------------------------------------------------------
+# convolution
+# --------------------------------------------------------------------------------------
+def _desc(ksize, stride, form, per_sample, algo=0):
+    return L.ConvDesc(ksize, stride, (ksize - 1) // 2, form, int(per_sample), algo)
+
+
+def conv_out_grid(shape, ksize, stride, transposed):
+    B, D, H, W, _ = shape
+    if transposed:
+        return B, D * stride, H * stride, W * stride
+    p = (ksize - 1) // 2
+    f = lambda n: (n + 2 * p - ksize) // stride + 1
+    return B, f(D), f(H), f(W)
+
+
+def pick_algo(x_shape, x_dtype, n_out, ksize, stride, transposed, per_sample, device, algo=0):
+    """(algo_fwd, algo_dgrad) the library resolves for this layer."""
+    B, Do, Ho, Wo = conv_out_grid(x_shape, ksize, stride, transposed)
+    xt = L.Tensor(1, L.dtype_code(x_dtype), x_shape[0], x_shape[1], x_shape[2], x_shape[3], x_shape[4], x_shape[4], 0)
+    yt = L.Tensor(1, L.dtype_code(x_dtype), B, Do, Ho, Wo, n_out, n_out, 0)
+    form = 1 if transposed else 0
+    a_f = lib.coma_conv_pick_algo(_desc(ksize, stride, form, per_sample, algo), xt, yt)
+    a_d = lib.coma_conv_pick_algo(_desc(ksize, stride, 1 - form, per_sample, algo), yt, xt)
+    return a_f, a_d
+
+
+class Conv(Function):
+    @staticmethod
+    def forward(ctx, x, wk_f, wk_d, bias, ksize, stride, transposed, per_sample, algo, out):
+        B, Do, Ho, Wo = conv_out_grid(x.shape, ksize, stride, transposed)
+        n = wk_f.shape[2]
+        y = out.t if out is not None else _new((B, Do, Ho, Wo, n), x.dtype, x.device)
+        form = 1 if transposed else 0
+        b = bias.contiguous().float() if bias is not None else None
+        KernelTimer.run("conv_fwd", "mfma" if wk_f.dtype == torch.bfloat16 else "direct",
+                        conv_flops(x.shape, y.shape, ksize, stride),
+                        lambda: check(lib.coma_conv_fwd(_desc(ksize, stride, form, per_sample, algo), ct(x), ptr(wk_f),
+                                                        L.dtype_code(wk_f.dtype), ptr(b), ct(y), L.stream()), "coma_conv_fwd"))
+        ctx.save_for_backward(x, wk_d)
+        ctx.meta = (ksize, stride, form, per_sample, algo, bias is not None, tuple(wk_f.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wk_d = ctx.saved_tensors
+        ksize, stride, form, per_sample, algo, has_bias, wshape = ctx.meta
+        dx = dwk = dbias = None
+        s = L.stream()
+        if ctx.needs_input_grad[0]:
+            assert wk_d is not None, "data gradient requested but dgrad weights were not prepared"
+            dx = torch.empty_like(x) if x.is_contiguous() else _new(x.shape, x.dtype, x.device)
+            KernelTimer.run("conv_dgrad", "mfma" if wk_d.dtype == torch.bfloat16 else "direct",
+                            conv_flops(dy.shape, dx.shape, ksize, stride),
+                            lambda: check(lib.coma_conv_fwd(_desc(ksize, stride, 1 - form, per_sample, algo), ct(dy),
+                                                            ptr(wk_d), L.dtype_code(wk_d.dtype), None, ct(dx), s),
+                                          "coma_conv_fwd(dgrad)"))
+        if ctx.needs_input_grad[1]:
+            d = _desc(ksize, stride, form, per_sample, algo)
+            cx, cdy = ct(x), ct(dy)
+            nb = lib.coma_conv_wgrad_ws_bytes(d, cx, cdy)
+            ws = workspace(nb, x.device)
+            dwk = _f32(wshape, x.device)
+            if has_bias:
+                dbias = _f32((x.shape[0], wshape[2]) if per_sample else (wshape[2],), x.device)
+            walgo = "mfma" if lib.coma_conv_wgrad_algo(d, cx, cdy) == 2 else "direct"
+            KernelTimer.run("conv_wgrad", walgo, conv_flops(x.shape, dy.shape, ksize, stride),
+                            lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias), ptr(ws), ws.numel(), s),
+                                          "coma_conv_wgrad"))
+        return dx, dwk, None, dbias, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------
+# BatchNorm (train) / InstanceNorm + activation
+# --------------------------------------------------------------------------------------
+class NormAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, rmean, rvar, mode, act, momentum, eps, training, out):
+        dev = x.device
+        B, C = x.shape[0], x.shape[4]
+        G = B if mode == L.NORM_INSTANCE else 1
+        cx = ct(x)
+        s = L.stream()
+        use_batch_stats = training or mode == L.NORM_INSTANCE
+        if use_batch_stats:
+            mean, rstd = _f32((G, C), dev), _f32((G, C), dev)
+            ws = workspace(lib.coma_norm_ws_bytes(cx), dev)
+            upd = rmean is not None and training
+            check(lib.coma_norm_stats(cx, mode, eps, ptr(mean), ptr(rstd), ptr(rmean) if upd else None,
+                                      ptr(rvar) if upd else None, momentum, ptr(ws), ws.numel(), s), "coma_norm_stats")
+        else:
+            mean = rmean.reshape(1, C).float().contiguous()
+            rstd = torch.rsqrt(rvar.reshape(1, C).float() + eps).contiguous()
+        y = out.t if out is not None else _new(x.shape, x.dtype, dev)
+        check(lib.coma_norm_act_fwd(cx, mode, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(slope), ct(y), s),
+              "coma_norm_act_fwd")
+        ctx.save_for_backward(x, mean, rstd, gamma, beta, slope)
+        ctx.meta = (mode, act, use_batch_stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta, slope = ctx.saved_tensors
+        mode, act, use_batch_stats = ctx.meta
+        if not use_batch_stats:
+            raise RuntimeError("backward through eval-mode BatchNorm is not part of the training path")
+        dev = x.device
+        C = x.shape[4]
+        dx = _new(x.shape, x.dtype, dev)
+        dgamma = _f32(C, dev) if gamma is not None else None
+        dbeta = _f32(C, dev) if beta is not None else None
+        dslope = _f32(1, dev) if slope is not None else None
+        cx = ct(x)
+        ws = workspace(lib.coma_norm_ws_bytes(cx), dev)
+        check(lib.coma_norm_act_bwd(cx, ct(dy), mode, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(slope),
+                                    ct(dx), ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(ws), ws.numel(), L.stream()),
+              "coma_norm_act_bwd")
+        return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------
+# attention gate pieces, strided add, concat-free join
+# --------------------------------------------------------------------------------------
+class AddRelu(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = _new(a.shape, a.dtype, a.device)
+        check(lib.coma_add_relu_fwd(ct(a), ct(b), ct(out), L.stream()), "coma_add_relu_fwd")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        da = _new(out.shape, out.dtype, out.device)
+        check(lib.coma_add_relu_bwd(ct(out), ct(dout), ct(da), L.stream()), "coma_add_relu_bwd")
+        return da, da
+
+
+class GateMul(Function):
+    """out = x * psi (psi broadcast over channels), attn_unet_data_parallel.py:150."""
+
+    @staticmethod
+    def forward(ctx, x, psi, out):
+        y = out.t if out is not None else _new(x.shape, x.dtype, x.device)
+        check(lib.coma_gate_mul_fwd(ct(x), ct(psi), ct(y), L.stream()), "coma_gate_mul_fwd")
+        ctx.save_for_backward(x, psi)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, psi = ctx.saved_tensors
+        dx = _new(x.shape, x.dtype, x.device)
+        dpsi = _new(psi.shape, psi.dtype, psi.device)
+        check(lib.coma_gate_mul_bwd(ct(x), ct(psi), ct(dout), ct(dx), 0, ct(dpsi), L.stream()), "coma_gate_mul_bwd")
+        return dx, dpsi, None
+
+
+class JoinSlices(Function):
+    """The parts were written straight into channel slices of `buf`; hand the whole buffer on.
+    Backward hands each producer its slice of the buffer's gradient (no copy either way)."""
+
+    @staticmethod
+    def forward(ctx, buf_holder, *parts):
+        ctx.widths = [p.shape[4] for p in parts]
+        return buf_holder.t
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        outs, c0 = [], 0
+        for w in ctx.widths:
+            outs.append(dbuf[..., c0:c0 + w])
+            c0 += w
+        return (None, *outs)
+
+
+class AddBcast(Function):
+    """dst = a + b where `a` may have batch 1 (a learned prompt broadcast over the batch,
+    attn_unet_data_parallel.py:640,651)."""
+
+    @staticmethod
+    def forward(ctx, a, b, out):
+        y = out.t if out is not None else _new(b.shape, b.dtype, b.device)
+        check(lib.coma_add(ct(a), ct(b), ct(y), L.stream()), "coma_add")
+        ctx.a_bcast = a.shape[0] == 1 and b.shape[0] > 1
+        ctx.a_shape = a.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        da = dy
+        if ctx.a_bcast:
+            da = _new(ctx.a_shape, dy.dtype, dy.device)
+            check(lib.coma_batch_sum(ct(dy), ct(da), L.stream()), "coma_batch_sum")
+        return da, dy, None
+
+
+class Copy(Function):
+    """Strided copy into a channel slice (out[..., k] of a concat buffer)."""
+
+    @staticmethod
+    def forward(ctx, a, out):
+        check(lib.coma_add(ct(a), None, ct(out.t), L.stream()), "coma_add(copy)")
+        return out.t
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+class SpatialMean(Function):
+    """AdaptiveAvgPool3d(1): (B, D, H, W, C) -> fp32 (B, C)  (attn_unet_data_parallel.py:538)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        cx = ct(x)
+        out = _f32((x.shape[0], x.shape[4]), x.device)
+        ws = workspace(lib.coma_norm_ws_bytes(cx), x.device)
+        check(lib.coma_spatial_mean(cx, ptr(out), ptr(ws), ws.numel(), L.stream()), "coma_spatial_mean")
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        # only reached with a zero-weighted loss term upstream (criterions.py:562); tiny broadcast
+        B, D, H, W, C = ctx.shape
+        g = (dout / float(D * H * W)).to(ctx.dtype).view(B, 1, 1, 1, C).expand(ctx.shape)
+        return g.contiguous()
+
+
+class RoiPaint(Function):
+    """cat((selected prompt, saliency volume, suvr volume)) of attn_unet_data_parallel.py:632-651."""
+
+    @staticmethod
+    def forward(ctx, pos_prompt, neg_prompt, roi, x, prior, roi_ids, abeta, out_dtype, need_pos=True, need_neg=True):
+        B, D, H, W, _ = x.shape
+        ctx.need = (need_pos, need_neg)
+        out3 = _new((B, D, H, W, 3), out_dtype, x.device)
+        check(lib.coma_roi_paint_fwd(ct(roi), ct(x), ptr(prior), ptr(roi_ids), roi_ids.numel(), ptr(abeta),
+                                     ptr(pos_prompt), ptr(neg_prompt), ct(out3), L.stream()), "coma_roi_paint_fwd")
+        ctx.save_for_backward(abeta)
+        ctx.pshape = pos_prompt.shape
+        return out3
+
+    @staticmethod
+    def backward(ctx, dout3):
+        (abeta,) = ctx.saved_tensors
+        dpos = torch.zeros(ctx.pshape, dtype=torch.float32, device=dout3.device)
+        dneg = torch.zeros(ctx.pshape, dtype=torch.float32, device=dout3.device)
+        check(lib.coma_roi_paint_bwd(ct(dout3), ptr(abeta), ptr(dpos), ptr(dneg), L.stream()), "coma_roi_paint_bwd")
+        # a prompt no sample selected gets grad None, as in the reference (:639) -> AdamW skips it
+        need_pos, need_neg = ctx.need
+        return (dpos if need_pos else None), (dneg if need_neg else None), None, None, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------
+class RoiMSELoss(Function):
+    """criterions.py:181-211 (voxel_wise=False): per-sample loss vector (B, 1)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, roi, roi_ids, roi_w):
+        B = pred.shape[0]
+        cp = ct(pred)
+        loss, mm = _f32(B, pred.device), _f32(B, pred.device)
+        ws = workspace(lib.coma_loss_ws_bytes(cp), pred.device)
+        check(lib.coma_roi_mse_fwd(cp, ct(gt), ct(roi), ptr(roi_ids), ptr(roi_w), roi_ids.numel(), ptr(loss), ptr(mm),
+                                   ptr(ws), ws.numel(), L.stream()), "coma_roi_mse_fwd")
+        ctx.save_for_backward(pred, gt, mm)
+        return loss.view(B, 1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, gt, mm = ctx.saved_tensors
+        g = gout.contiguous().float().view(-1)
+        dpred = torch.empty_like(pred)
+        check(lib.coma_roi_mse_bwd(ct(pred), ct(gt), ptr(g), ptr(mm), ct(dpred), L.stream()), "coma_roi_mse_bwd")
+        return dpred, None, None, None, None
+
+
+class L1Loss(Function):
+    """Per-sample voxel MAE (the reference's evaluation metric, attn_unet_data_parallel.py:1215)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt):
+        B = pred.shape[0]
+        cp = ct(pred)
+        loss = _f32(B, pred.device)
+        ws = workspace(lib.coma_loss_ws_bytes(cp), pred.device)
+        check(lib.coma_l1_fwd(cp, ct(gt), ptr(loss), ptr(ws), ws.numel(), L.stream()), "coma_l1_fwd")
+        ctx.save_for_backward(pred, gt)
+        return loss.view(B, 1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, gt = ctx.saved_tensors
+        g = gout.contiguous().float().view(-1)
+        dpred = torch.empty_like(pred)
+        check(lib.coma_l1_bwd(ct(pred), ct(gt), ptr(g), ct(dpred), L.stream()), "coma_l1_bwd")
+        return dpred, None
+
+
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step):
+    """In-place fused AdamW on flat fp32 buffers."""
+    assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32
+    check(lib.coma_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step, L.stream()),
+          "coma_adamw")

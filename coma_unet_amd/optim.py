@@ -1,0 +1,119 @@
+"""Fused AdamW on flat fp32 buffers (torch.optim.AdamW semantics; the reference builds
+``torch.optim.AdamW(model.parameters(), lr)``, attn_unet_data_parallel.py:736).
+
+Parameters that receive a gradient in the first step are packed into ONE flat parameter
+buffer and ONE flat gradient buffer (``p.data`` / ``p.grad`` become views), so a step is a
+single HBM-bound kernel launch and the data-parallel gradient exchange can all-reduce
+contiguous buckets of the same buffer.  Parameters whose gradient is ``None`` are skipped
+exactly as torch does (no decay, no moment update, no step count): the reference model has
+~75 such tensors ("aux model heads never used in forward").
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, dynamic=()):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        assert len(self.param_groups) == 1, "one parameter group (the reference uses one)"
+        self._dynamic = {id(p) for p in dynamic}   # may or may not get a gradient, step to step
+        self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
+        self._flat_params = []
+        self._flat_step = 0
+
+    # -- layout -------------------------------------------------------------------------
+    def _build(self):
+        ps = [p for p in self.param_groups[0]["params"] if p.grad is not None and id(p) not in self._dynamic]
+        assert ps, "no parameter has a gradient"
+        dev = ps[0].device
+        n = sum(p.numel() for p in ps)
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        self._offsets = {}
+        for p in ps:
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+            self.flat_g[off:off + k].copy_(p.grad.reshape(-1))
+            p.data = self.flat_p[off:off + k].view(p.shape)
+            p.grad = self.flat_g[off:off + k].view(p.shape)
+            self._offsets[id(p)] = (off, k)
+            off += k
+        self._flat_params = ps
+        self._flat_ids = {id(p) for p in ps}
+
+    @property
+    def built(self):
+        return self.flat_p is not None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.param_groups[0]["params"]:
+            if self.built and id(p) in self._flat_ids:
+                continue
+            p.grad = None
+        if self.built:
+            self.flat_g.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        g = self.param_groups[0]
+        lr, (b1, b2), eps, wd = float(g["lr"]), g["betas"], g["eps"], g["weight_decay"]
+        if not self.built:
+            self._build()
+        self._flat_step += 1
+        ops.adamw_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, lr, b1, b2, eps, wd, self._flat_step)
+        for p in g["params"]:
+            if id(p) in self._flat_ids or p.grad is None:
+                continue
+            st = self.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32)
+                st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
+            st["step"] += 1
+            gr = p.grad.float().contiguous()
+            ops.adamw_(p.data.view(-1), gr.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), lr, b1, b2, eps,
+                       wd, st["step"])
+
+    # -- torch.optim.AdamW-compatible checkpoint format (attn_unet_data_parallel.py:946-952) ----
+    def state_dict(self):
+        params = self.param_groups[0]["params"]
+        state = {}
+        for i, p in enumerate(params):
+            if self.built and id(p) in self._flat_ids:
+                off, k = self._offsets[id(p)]
+                state[i] = {"step": torch.tensor(float(self._flat_step)),
+                            "exp_avg": self.flat_m[off:off + k].view(p.shape).clone(),
+                            "exp_avg_sq": self.flat_v[off:off + k].view(p.shape).clone()}
+            elif p in self.state and self.state[p]:
+                st = self.state[p]
+                state[i] = {"step": torch.tensor(float(st["step"])), "exp_avg": st["exp_avg"].clone(),
+                            "exp_avg_sq": st["exp_avg_sq"].clone()}
+        pg = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        pg["params"] = list(range(len(params)))
+        return {"state": state, "param_groups": [pg]}
+
+    def load_state_dict(self, sd):
+        params = self.param_groups[0]["params"]
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                self.param_groups[0][k] = v
+        self._pending_state = sd["state"]
+        # moments are applied lazily: the flat layout exists only after the first backward
+        for i, st in sd["state"].items():
+            p = params[int(i)]
+            if self.built and id(p) in self._flat_ids:
+                off, k = self._offsets[id(p)]
+                self.flat_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.flat_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                self._flat_step = int(st["step"])
+            else:
+                self.state[p] = {"step": int(st["step"]), "exp_avg": st["exp_avg"].to(p.device).float().clone(),
+                                 "exp_avg_sq": st["exp_avg_sq"].to(p.device).float().clone()}

@@ -1,0 +1,174 @@
+/*
+ * coma_unet.h -- C ABI of the MI355X (gfx950) CoMA-UNet training hot path.
+ *
+ * Drop-in boundary.  The reference (mborhi/CoMA-UNet) is pure Python: its hot
+ * path is the nn.Module / criterion surface of
+ *   attn_unet_data_parallel.py:503-693  (ContrastiveAttentionUNET_DP)
+ *   attn_unet_data_parallel.py:779-912  (train_dp step body)
+ *   criterions.py:124-211,485-644       (RoiMSE, GenerativeContrastiveLoss, RnC)
+ * and it has no FFI of its own; every conv / norm / activation there is a
+ * cuDNN/ATen kernel that PyTorch dispatches.  This library is what replaces
+ * those dispatches: one entry point per row of SURVEY.md section 2.1.  The
+ * Python host (coma_unet_amd/) mirrors the reference's module surface and calls
+ * these functions through ctypes with raw device pointers.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers unless the name ends in _host.
+ *  - Activations are channels-last volumes "NDHWC": element (b, z, y, x, c) of
+ *    a coma_tensor t lives at  data + b*sb + ((z*H + y)*W + x)*ld + c  (in
+ *    elements of t.dtype).  ld >= C lets a tensor be a channel slice of a wider
+ *    buffer, which is how torch.cat((att, fromlower), dim=1)
+ *    (attn_unet_data_parallel.py:229,651,654) is done without a copy.
+ *  - Parameters, statistics and weight gradients are fp32.
+ *  - No function allocates, synchronises or keeps global state.  `stream` is a
+ *    hipStream_t passed as void*.  Return value 0 = ok, otherwise an error code;
+ *    coma_last_error() returns a thread-local message.
+ *  - Workspaces are caller-provided; the *_ws_bytes query says how much.
+ */
+#ifndef COMA_UNET_H
+#define COMA_UNET_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COMA_ABI_VERSION 1
+
+enum { COMA_F32 = 0, COMA_BF16 = 1 };
+
+/* activation after a normalisation (MONAI ADN "A" slot) */
+enum {
+  COMA_ACT_NONE = 0,
+  COMA_ACT_RELU = 1,        /* attentionunet.ConvBlock / UpConv                         */
+  COMA_ACT_PRELU = 2,       /* MONAI Convolution default, one shared slope             */
+  COMA_ACT_LEAKY = 3,       /* StackedFusionConvLayers, attn_unet_data_parallel.py:487 */
+  COMA_ACT_SIGMOID = 4,     /* AttentionBlock.psi                                       */
+  COMA_ACT_PRELU_RELU = 5   /* final_pred_head PReLU followed by final_act ReLU (:654-656) */
+};
+
+enum { COMA_NORM_BATCH = 0, COMA_NORM_INSTANCE = 1 };
+
+typedef struct coma_tensor {
+  void*   data;
+  int32_t dtype;          /* COMA_F32 | COMA_BF16 */
+  int32_t B, D, H, W, C;
+  int64_t ld;             /* elements between consecutive voxels (>= C)   */
+  int64_t sb;             /* elements between consecutive samples          */
+} coma_tensor;
+
+/* Gather form of a (transposed) convolution with a cubic kernel.
+ *   form 0 ("conv"):   in = out*stride - pad + tap       nn.Conv3d forward,
+ *                                                         ConvTranspose3d data-gradient
+ *   form 1 ("tconv"):  in = (out + pad - tap)/stride     nn.ConvTranspose3d forward,
+ *                       (only when divisible)             Conv3d data-gradient
+ * Kernel-layout weights are wk[b][tap][n][c] (c fastest), tap = (kz*k + ky)*k + kx. */
+typedef struct coma_conv_desc {
+  int32_t ksize;          /* 1 or 3 */
+  int32_t stride;         /* 1 or 2 */
+  int32_t pad;            /* 0 or 1 */
+  int32_t form;           /* 0 conv, 1 tconv */
+  int32_t per_sample_w;   /* 1: wk/bias have a leading B dim (CondConv) */
+  int32_t algo;           /* 0 auto, 1 direct (VALU fp32), 2 MFMA bf16 implicit GEMM */
+} coma_conv_desc;
+
+int         coma_abi_version(void);
+const char* coma_last_error(void);
+
+/* ---- CondConv expert mixing + weight re-layout  (replaces CondConv.CondConvolution's
+ *      per-sample kernel synthesis, call sites attn_unet_data_parallel.py:126,285-306) ----
+ * master: fp32 [E][..] with element (e, n, c, tap) at e*se + n*sn + c*sc + tap
+ * r: fp32 [Bw][E] routing weights, or NULL (=> Bw = 1, E = 1, plain re-layout/cast)
+ * out: [Bw][taps][N][C] in out_dtype                                              */
+int coma_weight_prep(const float* master, const float* r, int32_t E, int32_t Bw,
+                     int32_t N, int32_t C, int32_t taps, int64_t se, int64_t sn, int64_t sc,
+                     void* out, int32_t out_dtype, void* stream);
+/* dwk: fp32 [Bw][taps][N][C]  ->  dmaster (+=, fp32, master layout), dr [Bw][E] (=, fp32) */
+int coma_weight_prep_bwd(const float* dwk, const float* master, const float* r, int32_t E,
+                         int32_t Bw, int32_t N, int32_t C, int32_t taps, int64_t se,
+                         int64_t sn, int64_t sc, float* dmaster, float* dr, void* stream);
+
+/* ---- convolution (nn.Conv3d / nn.ConvTranspose3d and their data-gradients) ---- */
+/* which kernel family algo==0 resolves to for this problem: 1 direct (wants fp32 wk),
+ * 2 MFMA (wants bf16 wk).  The host prepares the kernel-layout weights accordingly.   */
+int coma_conv_pick_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
+int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
+                  int32_t wk_dtype, const float* bias, const coma_tensor* y, void* stream);
+/* dwk[b][tap][n][c] (=) sum_m dy[m][n] * x[pos(m,tap)][c]; fp32; batch-summed when
+ * !per_sample_w.  dbias[b][n] (=) sum_m dy[m][n] (may be NULL).                     */
+int coma_conv_wgrad_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
+size_t coma_conv_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
+int coma_conv_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy,
+                    float* dwk, float* dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- BatchNorm3d (train) / InstanceNorm3d + activation  (MONAI ADN "N","A") ---- */
+size_t coma_norm_ws_bytes(const coma_tensor* x);
+/* mean/rstd: fp32 [G][C], G = 1 (batch) or B (instance).  running_* may be NULL;
+ * updated as r = (1-momentum)*r + momentum*stat with the unbiased variance.      */
+int coma_norm_stats(const coma_tensor* x, int32_t mode, float eps, float* mean, float* rstd,
+                    float* running_mean, float* running_var, float momentum,
+                    void* ws, size_t ws_bytes, void* stream);
+/* y = act((x - mean)*rstd*gamma + beta); gamma/beta may be NULL; slope: device fp32[1] */
+int coma_norm_act_fwd(const coma_tensor* x, int32_t mode, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int32_t act, const float* slope,
+                      const coma_tensor* y, void* stream);
+/* dx (=); dgamma/dbeta [C] (=); dslope [1] (=); any of the three may be NULL */
+int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, int32_t mode,
+                      const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, int32_t act, const float* slope,
+                      const coma_tensor* dx, float* dgamma, float* dbeta, float* dslope,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---- attention gate pieces (MONAI AttentionBlock, attn_unet_data_parallel.py:139-150) ---- */
+/* out = relu(a + b);  da (=) db (=) dout * [out > 0] */
+int coma_add_relu_fwd(const coma_tensor* a, const coma_tensor* b, const coma_tensor* out, void* stream);
+int coma_add_relu_bwd(const coma_tensor* out, const coma_tensor* dout, const coma_tensor* da, void* stream);
+/* out[v][c] = x[v][c] * psi[v]   (psi has C == 1) */
+int coma_gate_mul_fwd(const coma_tensor* x, const coma_tensor* psi, const coma_tensor* out, void* stream);
+int coma_gate_mul_bwd(const coma_tensor* x, const coma_tensor* psi, const coma_tensor* dout,
+                      const coma_tensor* dx, int32_t accumulate_dx, const coma_tensor* dpsi, void* stream);
+
+/* ---- generic strided element-wise helpers ---- */
+/* dst = a (+ b).  b may be NULL.  a/b with B == 1 broadcast over dst's batch. */
+int coma_add(const coma_tensor* a, const coma_tensor* b, const coma_tensor* dst, void* stream);
+/* dst[0] (=) sum_b src[b]  (gradient of a batch-broadcast parameter) */
+int coma_batch_sum(const coma_tensor* src, const coma_tensor* dst, void* stream);
+/* per-sample, per-channel mean over voxels -> fp32 [B][C] (AdaptiveAvgPool3d(1)) */
+int coma_spatial_mean(const coma_tensor* x, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- ROI prior painting + prompt select (attn_unet_data_parallel.py:630-651) ----
+ * roi: fp32 labels (C==1); x: the MRI (C==1); prior: fp32 [B][n_roi][2] (loc,std);
+ * roi_ids: int32 [n_roi]; abeta: fp32 [B]; prompts: fp32, shape (1,D,H,W,1).
+ * out3: (B,D,H,W,3) = cat(prompt_sel, saliency, suvr)  with the x < 1e-4 zeroing.   */
+int coma_roi_paint_fwd(const coma_tensor* roi, const coma_tensor* x, const float* prior,
+                       const int32_t* roi_ids, int32_t n_roi, const float* abeta,
+                       const float* pos_prompt, const float* neg_prompt,
+                       const coma_tensor* out3, void* stream);
+/* dpos/dneg (+=, fp32 volumes): channel 0 of dout3 routed by abeta */
+int coma_roi_paint_bwd(const coma_tensor* dout3, const float* abeta, float* dpos, float* dneg, void* stream);
+
+/* ---- losses (criterions.py:181-211 RoiMSE voxel_wise=False; L1 = the MAE metric,
+ *      attn_unet_data_parallel.py:1215) ----
+ * loss[b] = mean_vox(mask_b) * mean_vox((pred_b - gt_b)^2), mask = weight LUT of roi */
+size_t coma_loss_ws_bytes(const coma_tensor* pred);
+int coma_roi_mse_fwd(const coma_tensor* pred, const coma_tensor* gt, const coma_tensor* roi,
+                     const int32_t* roi_ids, const float* roi_w, int32_t n_roi,
+                     float* loss, float* mask_mean, void* ws, size_t ws_bytes, void* stream);
+/* dpred (=) gout[b] * mask_mean[b] * 2 (pred - gt) / V */
+int coma_roi_mse_bwd(const coma_tensor* pred, const coma_tensor* gt, const float* gout,
+                     const float* mask_mean, const coma_tensor* dpred, void* stream);
+int coma_l1_fwd(const coma_tensor* pred, const coma_tensor* gt, float* loss, void* ws, size_t ws_bytes, void* stream);
+int coma_l1_bwd(const coma_tensor* pred, const coma_tensor* gt, const float* gout,
+                const coma_tensor* dpred, void* stream);
+
+/* ---- AdamW over a flat fp32 buffer (torch.optim.AdamW defaults,
+ *      attn_unet_data_parallel.py:736): p,g,m,v length n; step counted from 1 ---- */
+int coma_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+               float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMA_UNET_H */

@@ -1,0 +1,132 @@
+"""CPU-only checks (`-m "not gpu"`): the oracle against the golden fixtures, host logic, and that the
+C-ABI library loads and exports every symbol include/coma_unet.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    n = b.norm()
+    return float((a - b).norm() / n) if n > 0 else float((a - b).norm())
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "coma_unet.h")).read()
+    names = sorted(set(re.findall(r"\b(coma_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    so = os.path.join(ROOT, "coma_unet_amd", "libcoma_unet.so")
+    assert os.path.exists(so), "build the library first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(so)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in coma_unet.h but not exported"
+    lib.coma_abi_version.restype = ctypes.c_int
+    assert lib.coma_abi_version() == 1
+    from coma_unet_amd import _lib
+    assert sorted(_lib.SIGNATURES) == names, "ctypes binding table out of sync with the header"
+
+
+def test_product_package_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "coma_unet_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_oracle_losses_match_reference_golden():
+    """criterions_ref.npz was produced by the REFERENCE's own criterions.py (oracle/make_golden.py)."""
+    from oracle import criterions_oracle as orc
+    g = np.load(os.path.join(GOLD, "criterions_ref.npz"))
+    for ci in range(6):
+        feats = torch.from_numpy(g[f"rnc{ci}_features"]).requires_grad_(True)
+        labels = torch.from_numpy(g[f"rnc{ci}_labels"])
+        assert rel(orc.LabelDifference()(labels), g[f"rnc{ci}_labeldiff"]) < 1e-7
+        assert rel(orc.FeatureSimilarity()(feats), g[f"rnc{ci}_featsim"]) < 1e-7
+        loss = orc.RnCLoss()(feats, labels)
+        assert abs(float(loss) - float(g[f"rnc{ci}_loss"])) <= 1e-6 * max(1.0, abs(float(g[f"rnc{ci}_loss"])))
+        if torch.is_tensor(loss) and loss.requires_grad:
+            loss.backward()
+            assert rel(feats.grad, g[f"rnc{ci}_grad"]) < 1e-5
+    w = torch.from_numpy(g["gcl_w"])
+    from oracle.coma_oracle import ROI_INDICES
+    gen = orc.RoiMSE(w, ROI_INDICES)
+    gen.batch_reduction = None
+    crit = orc.GenerativeContrastiveLoss(orc.RnCLoss(), gen, torch.nn.TripletMarginLoss(1), 0.0, 1.0)
+    fin = torch.from_numpy(g["gcl_fin"])
+    tot, genl, ps, ds = crit(torch.from_numpy(g["gcl_pred"]), torch.from_numpy(g["gcl_gt"]), torch.from_numpy(g["gcl_roi"]),
+                             (fin, torch.zeros_like(fin), torch.zeros_like(fin)),
+                             (torch.from_numpy(g["gcl_feats"]), torch.from_numpy(g["gcl_labels"])))
+    assert abs(float(tot) - float(g["gcl_total"])) < 1e-5 * abs(float(g["gcl_total"]))
+    assert rel(genl, g["gcl_gen"]) < 1e-6 and abs(float(ds) - float(g["gcl_ds"])) < 1e-6
+
+
+def test_rnc_is_zero_at_batch_two():
+    from oracle import criterions_oracle as orc
+    f = torch.rand(2, 512)
+    assert float(orc.RnCLoss()(f, torch.rand(2, 6))) == 0.0
+
+
+def test_roimse_closed_form():
+    """loss_b = mean(mask_b) * mse_b (criterions.py:197-200)."""
+    from oracle import criterions_oracle as orc
+    from oracle.coma_oracle import ROI_INDICES
+    g = torch.Generator().manual_seed(0)
+    pred, gt = torch.rand((2, 1, 4, 4, 4), generator=g), torch.rand((2, 1, 4, 4, 4), generator=g)
+    roi = torch.zeros((2, 1, 4, 4, 4))
+    roi[0, 0, 0] = 17.0
+    roi[1, 0, :2] = 2034.0
+    m = orc.RoiMSE(torch.full((36,), 225.0), ROI_INDICES)
+    m.batch_reduction = None
+    l = m(pred, gt, roi)
+    exp0 = 225.0 * 16 / 64 * float(((pred[0] - gt[0]) ** 2).mean())
+    exp1 = 225.0 * 32 / 64 * float(((pred[1] - gt[1]) ** 2).mean())
+    assert abs(float(l[0]) - exp0) < 1e-4 and abs(float(l[1]) - exp1) < 1e-4
+
+
+def test_oracle_model_matches_golden_c1():
+    """BASELINE config C1: 32^3, batch 1, CPU forward (regression pin of the oracle itself)."""
+    from oracle.coma_oracle import build_reference_model
+    from coma_unet_amd.synthetic import make_batch
+    g = np.load(os.path.join(GOLD, "model32_oracle.npz"))
+    torch.manual_seed(101)
+    m = build_reference_model(volume_shape=(32, 32, 32))
+    m.set_save_attn(None)
+    m.train(True)
+    b = make_batch(1, (32, 32, 32), seed=8)
+    with torch.no_grad():
+        out = m(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])
+    assert rel(out[0], g["b1_out"]) < 1e-4
+    assert [tuple(p.shape) for p in out[1]] == [(1, 32768), (1, 4096), (1, 512), (1, 64), (1, 8)]
+    assert tuple(out[2].shape) == (1, 1, 1, 1, 2048)
+
+
+def test_synthetic_batch_contract():
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.roi_tables import ROI_INDICES
+    b = make_batch(2, (32, 32, 32), seed=1)
+    assert b["mri"].shape == (2, 1, 32, 32, 32) and b["mri"].dtype == torch.float32
+    assert b["covars"].shape == (2, 1, 6) and b["covars"].dtype == torch.float64
+    assert set(b["roi"].unique().tolist()) <= set([0.0, 2.0] + [float(i) for i in ROI_INDICES])
+    assert float((b["mri"][b["roi"] == 0]).abs().max()) == 0.0     # VolumeDataset_ADNI_A4_combined.py:68
+    assert len(b["roi_pred_dicts"]) == 2 and len(b["roi_pred_dicts"][0]) == 36
+    b2 = make_batch(2, (32, 32, 32), seed=1)
+    assert torch.equal(b["mri"], b2["mri"]) and torch.equal(b["roi"], b2["roi"])
+
+
+def test_hot_path_refuses_cpu_tensors():
+    """No CPU fallback: the product path must fail loudly without a device."""
+    import coma_unet_amd as cu
+    m = cu.build_model(volume_shape=(16, 16, 16))
+    m.set_save_attn(None)
+    from coma_unet_amd.synthetic import make_batch
+    b = make_batch(1, (16, 16, 16), seed=0)
+    with pytest.raises((AssertionError, RuntimeError)):
+        m(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])

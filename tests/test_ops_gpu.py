@@ -1,0 +1,290 @@
+"""Per-kernel parity: every C-ABI entry point against a CPU fp64 torch restatement of the
+same reference op (the ATen/MONAI op it replaces), on seeded inputs.  Tolerances: fp32 path
+1e-5 rel-L2 (summation-order differences only), bf16 path 2e-2 (bf16 storage rounding)."""
+import itertools
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from coma_unet_amd import ops, _lib
+    return ops, _lib
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    d = (a - b).norm()
+    n = b.norm()
+    return float(d / n) if n > 0 else float(d)
+
+
+def to_int(x):      # (B,C,D,H,W) -> (B,D,H,W,C) contiguous
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def to_ext(x):
+    return x.permute(0, 4, 1, 2, 3)
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+CONV_CASES = [
+    # cin, cout, k, stride, transposed, size
+    (1, 32, 3, 1, False, 10), (32, 32, 3, 1, False, 8), (32, 64, 3, 2, False, 8), (64, 32, 3, 2, True, 4),
+    (64, 32, 3, 1, False, 6), (32, 16, 1, 1, False, 6), (16, 1, 1, 1, False, 6), (3, 16, 3, 1, False, 7),
+    (16, 1, 3, 1, False, 6), (2, 8, 3, 1, False, 5), (8, 8, 3, 1, False, 5), (2, 1, 1, 1, False, 5),
+    (128, 64, 3, 2, True, 3), (64, 128, 3, 2, False, 6), (5, 7, 3, 2, False, 9), (7, 5, 3, 2, True, 5),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("per_sample", [False, True])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, per_sample, dtype):
+    ops, L = _ops()
+    cin, cout, k, s, tr, S = case
+    B, E = 2, 3
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    dims = (S, S + 1, S + 2) if not (s == 2 and not tr) else (S, S + 2, S + 4)
+    x = torch.randn((B, cin, *dims), generator=g, dtype=torch.float64)
+    wshape = (cin, cout, k, k, k) if tr else (cout, cin, k, k, k)
+    if per_sample:
+        master = torch.randn((E, *wshape), generator=g, dtype=torch.float64) * 0.2
+        r = torch.rand((B, E), generator=g, dtype=torch.float64)
+        bias = torch.randn((B, cout), generator=g, dtype=torch.float64)
+    else:
+        master = torch.randn(wshape, generator=g, dtype=torch.float64) * 0.2
+        r = None
+        bias = torch.randn((cout,), generator=g, dtype=torch.float64)
+    if dtype == torch.bfloat16:   # make inputs exactly representable so only accumulation differs
+        x = x.bfloat16().double()
+    xr = x.clone().requires_grad_(True)
+    mr = master.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if per_sample else None
+    br = bias.clone().requires_grad_(True)
+    p = (k - 1) // 2
+
+    def ref_conv(xb, w, b):
+        if tr:
+            return F.conv_transpose3d(xb, w, b, stride=s, padding=p, output_padding=s - 1)
+        return F.conv3d(xb, w, b, stride=s, padding=p)
+
+    if per_sample:
+        wmix = torch.einsum("be,e...->b...", rr, mr)
+        yr = torch.cat([ref_conv(xr[i:i + 1], wmix[i], br[i]) for i in range(B)], 0)
+    else:
+        yr = ref_conv(xr, mr, br)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().double()
+    yr.backward(gy)
+
+    dev = "cuda"
+    xi = to_int(x).to(dev, dtype).requires_grad_(True)
+    mg = master.float().to(dev).requires_grad_(True)
+    rg = r.float().to(dev).requires_grad_(True) if per_sample else None
+    bg = bias.float().to(dev).requires_grad_(True)
+    wk_f, wk_d = ops.PrepWeights.apply(mg, rg, tr, torch.float32, torch.float32)
+    y = ops.Conv.apply(xi, wk_f, wk_d, bg, k, s, tr, per_sample, 1, None)
+    assert rel(to_ext(y), yr) < TOL[dtype]
+    y.backward(to_int(gy).to(dev, dtype))
+    tol = TOL[dtype]
+    assert rel(to_ext(xi.grad), xr.grad) < tol
+    assert rel(mg.grad, mr.grad) < tol
+    assert rel(bg.grad, br.grad) < tol
+    if per_sample:
+        assert rel(rg.grad, rr.grad) < tol * 5
+
+
+ACTS = ["none", "relu", "prelu", "leaky", "sigmoid", "prelu_relu"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["batch", "instance"])
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("C", [1, 3, 16, 32, 96])
+def test_norm_act(C, act, mode, dtype):
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(C * 7 + len(act))
+    B, dims = 2, (5, 6, 7)
+    x = torch.randn((B, C, *dims), generator=g, dtype=torch.float64) * 1.5 + 0.7
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().double()
+    gamma = torch.rand((C,), generator=g, dtype=torch.float64) + 0.5
+    beta = torch.randn((C,), generator=g, dtype=torch.float64) * 0.3
+    slope = torch.tensor([-0.3 if act == "prelu_relu" else 0.2], dtype=torch.float64)
+    affine = mode == "batch"
+    xr, gr, br, sr = (t.clone().requires_grad_(True) for t in (x, gamma, beta, slope))
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    if mode == "batch":
+        z = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
+    else:
+        z = F.instance_norm(xr, eps=1e-5)
+    yr = {"none": lambda t: t, "relu": F.relu, "prelu": lambda t: F.prelu(t, sr),
+          "leaky": lambda t: F.leaky_relu(t, 0.01), "sigmoid": torch.sigmoid,
+          "prelu_relu": lambda t: F.relu(F.prelu(t, sr))}[act](z)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().double()
+    yr.backward(gy)
+
+    dev = "cuda"
+    xi = to_int(x).to(dev, dtype).requires_grad_(True)
+    gg = gamma.float().to(dev).requires_grad_(True) if affine else None
+    bg = beta.float().to(dev).requires_grad_(True) if affine else None
+    sg = slope.float().to(dev).requires_grad_(True) if act in ("prelu", "prelu_relu") else None
+    rmg = torch.zeros(C, device=dev) if affine else None
+    rvg = torch.ones(C, device=dev) if affine else None
+    code = {"none": L.ACT_NONE, "relu": L.ACT_RELU, "prelu": L.ACT_PRELU, "leaky": L.ACT_LEAKY,
+            "sigmoid": L.ACT_SIGMOID, "prelu_relu": L.ACT_PRELU_RELU}[act]
+    y = ops.NormAct.apply(xi, gg, bg, sg, rmg, rvg, L.NORM_BATCH if affine else L.NORM_INSTANCE, code, 0.1, 1e-5, True, None)
+    tol = TOL[dtype]
+    assert rel(to_ext(y), yr) < tol
+    y.backward(to_int(gy).to(dev, dtype))
+    assert rel(to_ext(xi.grad), xr.grad) < tol * 3
+    if affine:
+        assert rel(gg.grad, gr.grad) < tol * 3
+        assert rel(bg.grad, br.grad) < tol * 3
+        assert rel(rmg, rm) < 1e-5 and rel(rvg, rv) < 1e-5
+    if sg is not None:
+        assert rel(sg.grad, sr.grad) < tol * 3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [32, 64, 256])
+def test_gate_pieces(C, dtype):
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(C)
+    B, dims = 2, (4, 5, 6)
+    mk = lambda c: (torch.randn((B, c, *dims), generator=g, dtype=torch.float64)).to(dtype).double()
+    a, b, x, psi = mk(C), mk(C), mk(C), torch.sigmoid(mk(1))
+    psi = psi.to(dtype).double()
+    ar, br, xr, pr = (t.clone().requires_grad_(True) for t in (a, b, x, psi))
+    out_r = F.relu(ar + br) * 1.0
+    att_r = xr * pr
+    gy1, gy2 = mk(C), mk(C)
+    (out_r * gy1).sum().backward()
+    (att_r * gy2).sum().backward()
+    dev = "cuda"
+    ai, bi, xi, pi = (to_int(t).to(dev, dtype).requires_grad_(True) for t in (a, b, x, psi))
+    out = ops.AddRelu.apply(ai, bi)
+    # write the gate output into a channel slice of a wider buffer (concat-free path)
+    cat = torch.zeros((B, *dims, 2 * C), device=dev, dtype=dtype)
+    att = ops.GateMul.apply(xi, pi, ops.Out(cat[..., :C]))
+    tol = TOL[dtype]
+    assert rel(to_ext(out), out_r) < tol and rel(to_ext(att), att_r) < tol
+    assert float(cat[..., C:].abs().max()) == 0.0
+    out.backward(to_int(gy1).to(dev, dtype))
+    att.backward(to_int(gy2).to(dev, dtype))
+    assert rel(to_ext(ai.grad), ar.grad) < tol and rel(to_ext(bi.grad), br.grad) < tol
+    assert rel(to_ext(xi.grad), xr.grad) < tol
+    assert rel(to_ext(pi.grad), pr.grad) < tol * 3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_roi_paint_and_losses(dtype):
+    ops, L = _ops()
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.roi_tables import ROI_INDICES, ROI_INDEX_TO_NAME
+    from oracle.criterions_oracle import RoiMSE as ORoiMSE
+    B, S = 3, (8, 10, 12)
+    b = make_batch(B, S, seed=5)
+    dev = "cuda"
+    g = torch.Generator().manual_seed(1)
+    pos = torch.randn((1, 1, *S), generator=g)
+    neg = torch.randn((1, 1, *S), generator=g)
+    prior = torch.tensor([[[d[ROI_INDEX_TO_NAME[i]]["loc"], d[ROI_INDEX_TO_NAME[i]]["std"]] for i in ROI_INDICES]
+                          for d in b["roi_pred_dicts"]], dtype=torch.float32)
+    abeta = b["covars"][:, 0, 0].float()
+    # oracle painting (attn_unet_data_parallel.py:630-651)
+    x = b["mri"].to(dtype).float()
+    suvr = torch.zeros_like(x)
+    sal = torch.zeros_like(x)
+    for bb in range(B):
+        for i, idx in enumerate(ROI_INDICES):
+            m = b["roi"][bb] == idx
+            suvr[bb][m] = prior[bb, i, 0]
+            sal[bb][m] = prior[bb, i, 1]
+    suvr = torch.where(x < 1e-4, torch.zeros_like(suvr), suvr)
+    sal = torch.where(x < 1e-4, torch.zeros_like(sal), sal)
+    dyn = torch.vstack([pos if abeta[bb] == 1 else neg for bb in range(B)])
+    ref3 = torch.cat((dyn, sal, suvr), dim=1)
+    posg, negg = pos.to(dev).requires_grad_(True), neg.to(dev).requires_grad_(True)
+    ids = torch.tensor(ROI_INDICES, dtype=torch.int32, device=dev)
+    out3 = ops.RoiPaint.apply(posg, negg, to_int(b["roi"]).to(dev), to_int(b["mri"]).to(dev, dtype), prior.to(dev), ids,
+                              abeta.to(dev), dtype)
+    assert rel(to_ext(out3), ref3.to(dtype)) < 1e-6
+    gy = torch.randn(ref3.shape, generator=g)
+    out3.backward(to_int(gy).to(dev, dtype))
+    gyq = gy.to(dtype).float()
+    dpos = sum(gyq[bb, 0] for bb in range(B) if abeta[bb] == 1)
+    dneg = sum(gyq[bb, 0] for bb in range(B) if abeta[bb] != 1)
+    if torch.is_tensor(dpos):
+        assert rel(posg.grad[0, 0], dpos) < 1e-5
+    if torch.is_tensor(dneg):
+        assert rel(negg.grad[0, 0], dneg) < 1e-5
+    # RoiMSE
+    w = torch.full((36,), 225.0)
+    w[5] = 17.0
+    pred = torch.rand((B, 1, *S), generator=g).to(dtype)
+    predr = pred.double().requires_grad_(True)
+    orc = ORoiMSE(w.double(), ROI_INDICES)
+    orc.batch_reduction = None
+    lr = orc(predr, b["tau"].to(dtype).double(), b["roi"].double())
+    cw = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64).view(B, 1)
+    (lr * cw).sum().backward()
+    pg = to_int(pred).to(dev).requires_grad_(True)
+    lg = ops.RoiMSELoss.apply(pg, to_int(b["tau"]).to(dev, dtype), to_int(b["roi"]).to(dev), ids, w.to(dev))
+    assert rel(lg, lr) < 1e-5
+    (lg * cw.float().to(dev)).sum().backward()
+    assert rel(to_ext(pg.grad), predr.grad) < TOL[dtype]
+    # L1
+    predr2 = pred.double().requires_grad_(True)
+    l1r = (predr2 - b["tau"].to(dtype).double()).abs().mean(dim=(-3, -2, -1))
+    (l1r * cw).sum().backward()
+    pg2 = to_int(pred).to(dev).requires_grad_(True)
+    l1g = ops.L1Loss.apply(pg2, to_int(b["tau"]).to(dev, dtype))
+    assert rel(l1g, l1r) < 1e-5
+    (l1g * cw.float().to(dev)).sum().backward()
+    assert rel(to_ext(pg2.grad), predr2.grad) < TOL[dtype]
+
+
+def test_add_bcast_copy_mean():
+    ops, L = _ops()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn((1, 4, 5, 6, 1), generator=g).to(dev).requires_grad_(True)
+    b = torch.randn((3, 4, 5, 6, 1), generator=g).to(dev).requires_grad_(True)
+    cat = torch.zeros((3, 4, 5, 6, 2), device=dev)
+    y = ops.AddBcast.apply(a, b, ops.Out(cat[..., 0:1]))
+    assert rel(y, a.detach() + b.detach()) < 1e-7
+    c = ops.Copy.apply(b, ops.Out(cat[..., 1:2]))
+    assert rel(cat[..., 1:2], b) == 0.0
+    gy = torch.randn((3, 4, 5, 6, 1), generator=g).to(dev)
+    (y * gy).sum().backward()
+    assert rel(a.grad, gy.sum(0, keepdim=True)) < 1e-6 and rel(b.grad, gy) < 1e-7
+    x = torch.randn((2, 6, 7, 8, 5), generator=g).to(dev)
+    m = ops.SpatialMean.apply(x)
+    assert rel(m, x.mean(dim=(1, 2, 3))) < 1e-6
+
+
+def test_adamw_matches_torch():
+    ops, L = _ops()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(10007, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        gr = torch.randn(10007, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        ops.adamw_(p, gr.to(dev), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step)
+    assert rel(p, pr) < 1e-6
