@@ -150,11 +150,11 @@ def main():
             "roofline": roof, "conv_kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, 64)
             try:
                 threads = len(os.sched_getaffinity(0))
             except Exception:
-                pass
+                threads = os.cpu_count() or 1
+            threads = min(threads, 16)   # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
             line["cpu_baseline"] = cpu_baseline(args.size, threads)
         else:
             line["cpu_baseline"] = None

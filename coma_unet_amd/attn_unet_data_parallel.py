@@ -238,8 +238,10 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         self.depth = len(channels)
         vs = tuple(kwargs.get("volume_shape", (128, 128, 128)))
         self.volume_shape = vs
+        # the duplicated pass of :664/:666 covers the U-Net only; the heads run once per forward
+        cfg1 = Config(cfg.compute_dtype, cfg.conv_algo, 1)
         self.projection_heads = nn.ModuleList(
-            [ProjectionHead(cfg, channels[i], int((128 / (2 ** i)) ** 3), latent_spaces[i]) for i in range(len(channels))])
+            [ProjectionHead(cfg1, channels[i], int((128 / (2 ** i)) ** 3), latent_spaces[i]) for i in range(len(channels))])
         self.final_projection_head = nn.Sequential(nn.AdaptiveAvgPool3d(1), nn.Linear(out_channels, latent_spaces[-1]), nn.ReLU())
         self.pos_dynamic_prompt = nn.Parameter(torch.randn(1, 1, *vs))
         self.neg_dynamic_prompt = nn.Parameter(torch.randn(1, 1, *vs))

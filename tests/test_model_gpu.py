@@ -3,8 +3,9 @@
 
 Tolerances: forward/loss vs the fp32 oracle <= 1e-3 rel-L2 (north_star's bound; measured ~1e-5).
 Gradients are compared with the fp64 oracle: through ~45 conv+norm layers at batch 2 the
-backward pass is ill-conditioned in fp32 -- the fp32 CPU oracle itself is ~2e-3 away from its
-own fp64 run -- so the bound is 2e-2 on every tensor whose gradient is not rounding noise.
+backward pass is ill-conditioned in fp32 -- the fp32 CPU oracle itself is 2e-3..5e-2 away from
+its own fp64 run (worst at the 4^3 bottom levels) -- so the bound per tensor is
+max(2e-2, 4 x the fp32 CPU oracle's own error) on every gradient that is not rounding noise.
 """
 import copy
 import os
@@ -73,17 +74,21 @@ def test_c1_forward_loss_backward_vs_oracle_and_golden(B):
     tot = train_step_loss(res, b["tau"].double(), b["roi"].double(), b["covars"], build_reference_criterion())[0]
     tot.backward()
     assert rel(outs[0], res[0]) < 1e-4
+    # the fp32 CPU oracle's own distance from fp64 is the yardstick for "as accurate as the reference"
+    r32 = om(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])
+    train_step_loss(r32, b["tau"], b["roi"], b["covars"], build_reference_criterion())[0].backward()
+    o32g = dict(om.named_parameters())
     og = dict(o64.named_parameters())
-    worst = 0.0
+    worst = worst_cpu = 0.0
     for n, p in gm.named_parameters():
         r = og[n].grad
         assert (p.grad is None) == (r is None), n
         if r is None or float(r.norm()) < 1e-4 * max(1.0, float(og[n].norm())):
             continue   # conv biases in front of a norm: mathematically zero, rounding noise in both
-        e = rel(p.grad, r)
-        worst = max(worst, e)
-        assert e < 2e-2, (n, e)
-    print(f"worst relative gradient error vs fp64 oracle: {worst:.2e}")
+        e, e_cpu = rel(p.grad, r), rel(o32g[n].grad, r)
+        worst, worst_cpu = max(worst, e), max(worst_cpu, e_cpu)
+        assert e < max(2e-2, 4.0 * e_cpu), (n, e, e_cpu)
+    print(f"worst relative gradient error vs fp64 oracle: HIP fp32 {worst:.2e}, CPU fp32 oracle {worst_cpu:.2e}")
 
 
 def test_eval_mode_uses_double_updated_running_stats():
@@ -102,7 +107,7 @@ def test_eval_mode_uses_double_updated_running_stats():
         if "running_" in k:
             assert rel(gsd[k], osd[k]) < 1e-4, k
         if "num_batches_tracked" in k:
-            assert int(gsd[k]) == int(osd[k]) == 2, k
+            assert int(gsd[k]) == int(osd[k]) == (2 if k.startswith("model.") else 1), k
     om.eval(), gm.eval()
     with torch.no_grad():
         eo = om(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])
