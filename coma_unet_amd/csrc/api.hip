@@ -31,8 +31,8 @@ int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_te
                     size_t ws_bytes, hipStream_t s);
 
 extern "C" int coma_conv_pick_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
-  if (d->algo) return d->algo;
-  return conv_mfma_supported(d, x, y) ? 2 : 1;
+  if (d->algo == 1) return 1;
+  return conv_mfma_supported(d, x, y) ? 2 : 1;   // algo 2 = "MFMA wherever the shape allows"
 }
 
 extern "C" int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
@@ -52,7 +52,7 @@ extern "C" int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, cons
 }
 
 extern "C" int coma_conv_wgrad_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
-  if (d->algo) return d->algo;
+  if (d->algo == 1) return 1;
   return (x->dtype == COMA_BF16 && conv_mfma_wgrad_supported(d, x, dy)) ? 2 : 1;
 }
 

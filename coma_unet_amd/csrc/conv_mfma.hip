@@ -1,9 +1,493 @@
-// placeholder until the MFMA implicit-GEMM kernels land
+// bf16 MFMA implicit-GEMM convolution kernels for gfx950 (CDNA4, wave64).
+//
+//   y[m][n] = sum_tap sum_c x[pos(m, tap)][c] * wk[tap][n][c]      (fp32 accumulate)
+//
+// GEMM view: M = output voxels (one sample per blockIdx.z), N = output channels, K = taps x C.
+// Operands are staged through LDS as [row][32 channels] bf16 tiles (64-byte rows, 16-byte chunks
+// XOR-swizzled by (row >> 2) & 3 so that the ds_read_b128 fragment reads of v_mfma_f32_32x32x16_bf16
+// are bank-conflict free), double-buffered with register prefetch of the next K-step.
+//
+// Replaces the cuDNN dispatches behind nn.Conv3d / nn.ConvTranspose3d forward and data-gradient
+// in the reference model (attn_unet_data_parallel.py; MONAI Convolution / CondConv call sites).
 #include "common.h"
-bool conv_mfma_supported(const coma_conv_desc*, const coma_tensor*, const coma_tensor*) { return false; }
-int conv_mfma_fwd(const coma_conv_desc*, const coma_tensor*, const void*, const float*, const coma_tensor*, hipStream_t) {
-  coma_set_error("MFMA conv not built"); return 3; }
-bool conv_mfma_wgrad_supported(const coma_conv_desc*, const coma_tensor*, const coma_tensor*) { return false; }
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one MFMA A/B fragment
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 accumulator fragment
+
+struct GatherP {
+  const bf16_t* x; int ldx; long sbx; int Di, Hi, Wi, C;
+  bf16_t* y; int ldy; long sby; int Do, Ho, Wo, N;
+  const bf16_t* w; long wsb;          // [b][tap][N][C]
+  const float* bias; int bsb;
+  int k, stride, flip;
+  int Mz, My, Mx;                      // M-grid (MODE 0: output grid; MODE 1: coarse grid)
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 2) | (chunk ^ ((row >> 2) & 3)); }  // 16-B slot index
+
+// MODE 0: in = m*stride - pad + tap  (all taps; `flip` mirrors the weight tap index)
+// MODE 1: stride-2 transposed gather, one output-parity class per blockIdx.y slice
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
+  constexpr int BM = (BN == 128) ? 128 : 256;
+  constexpr int WAVES_N = (BN == 128) ? 2 : 1;
+  constexpr int NT = BN / 32 / WAVES_N;           // N-tiles per wave
+  constexpr int MT = 2;                           // M-tiles per wave (64 rows)
+  constexpr int A_PIECES = BM * 4 / 256;          // 16-B pieces per thread
+  constexpr int B_PIECES = (BN * 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* ldsA = reinterpret_cast<uint4*>(smem);                       // [2][BM*4]
+  uint4* ldsB = ldsA + 2 * BM * 4;                                    // [2][BN*4]
+  int* rowoff = reinterpret_cast<int*>(ldsB + 2 * BN * 4);            // [BM] output element offset or -1
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int b = blockIdx.z;
+  int nblk, cls = 0;
+  if (MODE == 1) { cls = blockIdx.y & 7; nblk = blockIdx.y >> 3; } else { nblk = blockIdx.y; }
+  const int n0 = nblk * BN;
+  const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+  const long Mtot = (long)p.Mz * p.My * p.Mx;
+  const long m0 = (long)blockIdx.x * BM;
+  const bf16_t* xb = p.x + (long)b * p.sbx;
+  const bf16_t* wb = p.w + (long)b * p.wsb;
+  const int pad = (p.k - 1) >> 1;
+
+  // ---- per-thread gather rows (fixed over the K loop) ----
+  const int chunk = tid & 3;
+  int rz[A_PIECES], ry[A_PIECES], rx[A_PIECES];   // base input coordinates (tap 0 / delta 0)
+#pragma unroll
+  for (int i = 0; i < A_PIECES; ++i) {
+    const int row = (tid >> 2) + 64 * i;
+    const long m = m0 + row;
+    if (m < Mtot) {
+      const int mx = (int)(m % p.Mx), my = (int)((m / p.Mx) % p.My), mz = (int)(m / ((long)p.Mx * p.My));
+      if (MODE == 0) { rz[i] = mz * p.stride - pad; ry[i] = my * p.stride - pad; rx[i] = mx * p.stride - pad; }
+      else { rz[i] = mz; ry[i] = my; rx[i] = mx; }
+      if (chunk == 0) {
+        int off;
+        if (MODE == 0) off = (int)(m * p.ldy);
+        else {
+          const int oz = 2 * mz + pz, oy = 2 * my + py, ox = 2 * mx + px;
+          off = (oz < p.Do && oy < p.Ho && ox < p.Wo) ? (((oz * p.Ho + oy) * p.Wo + ox) * p.ldy) : -1;
+        }
+        rowoff[row] = off;
+      }
+    } else {
+      rz[i] = ry[i] = rx[i] = -(1 << 20);
+      if (chunk == 0) rowoff[row] = -1;
+    }
+  }
+
+  // ---- K loop bookkeeping ----
+  const int cchunks = p.C >> 5;
+  int ntaps;
+  if (MODE == 0) ntaps = p.k * p.k * p.k; else ntaps = (1 + pz) * (1 + py) * (1 + px);
+  const int nsteps = ntaps * cchunks;
+
+  uint4 ra[A_PIECES], rb[B_PIECES];
+  auto load_step = [&](int step) {
+    const int t = step / cchunks, cc = step - t * cchunks;
+    int dz, dy, dx, wtap;
+    if (MODE == 0) {
+      const int kx = t % p.k, ky = (t / p.k) % p.k, kz = t / (p.k * p.k);
+      dz = kz; dy = ky; dx = kx;
+      wtap = p.flip ? (ntaps - 1 - t) : t;
+    } else {
+      // per dim: parity 0 -> tap 1, delta 0 ; parity 1 -> j=0: tap 0, delta +1 ; j=1: tap 2, delta 0
+      const int nx = 1 + px, ny = 1 + py;
+      const int jx = t % nx, jy = (t / nx) % ny, jz = t / (nx * ny);
+      const int tx = px ? (jx ? 2 : 0) : 1, ty = py ? (jy ? 2 : 0) : 1, tz = pz ? (jz ? 2 : 0) : 1;
+      dx = px ? (jx ? 0 : 1) : 0; dy = py ? (jy ? 0 : 1) : 0; dz = pz ? (jz ? 0 : 1) : 0;
+      wtap = (tz * 3 + ty) * 3 + tx;
+    }
+    const int c0 = (cc << 5) + (chunk << 3);
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+      const int iz = rz[i] + dz, iy = ry[i] + dy, ix = rx[i] + dx;
+      const bool ok = (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (ok) ra[i] = *reinterpret_cast<const uint4*>(xb + (long)((iz * p.Hi + iy) * p.Wi + ix) * p.ldx + c0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+      const int piece = tid + 256 * i;
+      const int n = piece >> 2;
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (n < BN) rb[i] = *reinterpret_cast<const uint4*>(wb + ((long)wtap * p.N + n0 + n) * p.C + c0);
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) ldsA[buf * BM * 4 + swz((tid >> 2) + 64 * i, chunk)] = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+      const int piece = tid + 256 * i;
+      const int n = piece >> 2;
+      if (n < BN) ldsB[buf * BN * 4 + swz(n, chunk)] = rb[i];
+    }
+  };
+
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  int cur = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    if (step + 1 < nsteps) load_step(step + 1);
+    const uint4* A = ldsA + cur * BM * 4;
+    const uint4* B = ldsB + cur * BN * 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[MT], bfr[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const uint4 v = A[swz(wm * 64 + i * 32 + fr, ks * 2 + fh)];
+        af[i] = *reinterpret_cast<const bf16x8_t*>(&v);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const uint4 v = B[swz(wn * (NT * 32) + j * 32 + fr, ks * 2 + fh)];
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(&v);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (step + 1 < nsteps) store_step(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: + bias, cast, store (row = voxel, lane column = channel) ----
+  bf16_t* yb = p.y + (long)b * p.sby;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * (NT * 32) + j * 32 + fr;
+    const float bv = p.bias ? p.bias[b * p.bsb + n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int off = rowoff[row];
+        if (off >= 0) yb[off + n] = static_cast<bf16_t>(acc[i][j][e] + bv);
+      }
+    }
+  }
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  if (x->dtype != COMA_BF16 || y->dtype != COMA_BF16) return false;
+  if (x->C % 32 || y->C % 32) return false;
+  if (x->ld % 8 || y->ld % 8 || x->sb % 8 || y->sb % 8) return false;
+  if (x->data && !aligned16(x->data)) return false;
+  if ((long)t_vox(x) * x->ld >= (1L << 31) || (long)t_vox(y) * y->ld >= (1L << 31)) return false;
+  if (d->form == 1 && d->stride == 2 && d->ksize != 3) return false;
+  return true;
+}
+
+template <int BN>
+static int launch_gather(const GatherP& p, int mode, int B, hipStream_t s) {
+  constexpr int BM = (BN == 128) ? 128 : 256;
+  const long Mtot = (long)p.Mz * p.My * p.Mx;
+  const size_t lds = (size_t)2 * (BM + BN) * 64 + BM * 4;
+  dim3 grid((unsigned)((Mtot + BM - 1) / BM), (unsigned)(p.N / BN) * (mode == 1 ? 8 : 1), (unsigned)B);
+  if (mode == 0) hipLaunchKernelGGL((conv_mfma_gather_k<BN, 0>), grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL((conv_mfma_gather_k<BN, 1>), grid, dim3(256), lds, s, p);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
+int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
+                  const coma_tensor* y, hipStream_t s) {
+  COMA_CHECK(aligned16(wk) && aligned16(x->data), "conv_mfma: operands must be 16-byte aligned");
+  GatherP p;
+  p.x = (const bf16_t*)x->data; p.ldx = (int)x->ld; p.sbx = x->sb; p.Di = x->D; p.Hi = x->H; p.Wi = x->W; p.C = x->C;
+  p.y = (bf16_t*)y->data; p.ldy = (int)y->ld; p.sby = y->sb; p.Do = y->D; p.Ho = y->H; p.Wo = y->W; p.N = y->C;
+  const int taps = d->ksize * d->ksize * d->ksize;
+  p.w = (const bf16_t*)wk; p.wsb = d->per_sample_w ? (long)taps * y->C * x->C : 0;
+  p.bias = bias; p.bsb = d->per_sample_w ? y->C : 0;
+  p.k = d->ksize; p.stride = d->stride; p.flip = 0;
+  int mode = 0;
+  if (d->form == 1 && d->stride == 1) { p.flip = 1; }
+  if (d->form == 1 && d->stride == 2) {
+    mode = 1;
+    p.Mz = (y->D + 1) / 2; p.My = (y->H + 1) / 2; p.Mx = (y->W + 1) / 2;
+  } else {
+    p.Mz = y->D; p.My = y->H; p.Mx = y->W;
+  }
+  if (y->C % 128 == 0) return launch_gather<128>(p, mode, x->B, s);
+  if (y->C % 64 == 0) return launch_gather<64>(p, mode, x->B, s);
+  return launch_gather<32>(p, mode, x->B, s);
+}
+
+// =====================================================================================
+// Weight gradient on MFMA:  dwk[b][tap][n][c] = sum_m dy[.][n] * x[.][c]  over the voxels m of
+// the M-grid, one operand read densely and the other through a tap-shifted (strided) gather:
+//   FORM 0 (nn.Conv3d):          dense = dy[m],  gathered = x[m*stride - pad + tap]
+//   FORM 1 (nn.ConvTranspose3d): dense = x[m],   gathered = dy[m*2 - pad + tap]
+// A block stages one tile of dense voxels and the matching halo of the gathered tensor in LDS
+// as [voxel][channel] images, then every tap re-reads the SAME halo at its shifted address: the
+// 27-fold operand reuse happens in LDS, not in L2/HBM.  The GEMM reduction index is the voxel,
+// so both MFMA operands are read with ds_read_b64_tr_b16 (4 voxels x 16 channels per 16-lane
+// group, delivered channel-per-lane).  The 27 taps are dealt to the 4 waves (7,7,7,6); each wave
+// keeps its taps' 32x32 fp32 accumulators in registers across all tiles of the block
+// (weight-gradient-stationary) and merges them into dwk with fp32 atomics at the end.
+// =====================================================================================
+typedef __attribute__((ext_vector_type(4))) short s4_t;
+typedef __attribute__((address_space(3))) s4_t lds_s4_t;
+
+struct WgradP2 {
+  const bf16_t* dyp; int ldn; long sbn;     // dy  (N channels)
+  const bf16_t* xp;  int ldc; long sbc;     // x   (C channels)
+  int N, C;
+  int Mz, My, Mx;      // dense grid
+  int Gz, Gy, Gx;      // gathered grid
+  int k, stride, pad;
+  int lx, ly, lz;      // log2 of the tile dims (tile = 2^lz x 2^ly x 2^lx dense voxels)
+  int hz, hy, hx;      // halo dims
+  int ntx, nty, ntz;   // tiles per dim
+  int tiles_total, tiles_per_block;
+  float* dwk; long wsb;
+  int cblocks;         // ceil(C / (32*TC))
+  int vec_n, vec_c;    // 16-byte loads legal on dy / x
+};
+
+// 8 channels starting at `ptr`, of which `nvalid` exist; `vec` = 16-byte access is legal
+__device__ __forceinline__ uint4 load8(const bf16_t* ptr, int nvalid, bool vec) {
+  if (vec && nvalid >= 8) return *reinterpret_cast<const uint4*>(ptr);
+  unsigned short e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = j < nvalid ? reinterpret_cast<const unsigned short*>(ptr)[j] : (unsigned short)0;
+  return make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                    e[6] | ((unsigned)e[7] << 16));
+}
+
+template <int TN, int TC, int FORM>
+__global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
+  constexpr int CDB = 32 * (FORM == 0 ? TN : TC);   // dense-side channels per block
+  constexpr int CGB = 32 * (FORM == 0 ? TC : TN);   // gathered-side channels per block
+  constexpr int PD = CDB * 2, PG = CGB * 2;         // LDS row pitches (bytes)
+  constexpr int MAXT = 7;                           // taps per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int TM = 1 << (p.lx + p.ly + p.lz);
+  char* Dt = smem;
+  char* Gt = smem + TM * PD;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.z;
+  const int nb = blockIdx.y / p.cblocks, cb = blockIdx.y % p.cblocks;
+  const int n0 = nb * 32 * TN, c0 = cb * 32 * TC;
+  const bf16_t* dense = (FORM == 0 ? p.dyp + (long)b * p.sbn + n0 : p.xp + (long)b * p.sbc + c0);
+  const bf16_t* gath = (FORM == 0 ? p.xp + (long)b * p.sbc + c0 : p.dyp + (long)b * p.sbn + n0);
+  const int ldd = FORM == 0 ? p.ldn : p.ldc, ldg = FORM == 0 ? p.ldc : p.ldn;
+  const int chd = (FORM == 0 ? p.N - n0 : p.C - c0), chg = (FORM == 0 ? p.C - c0 : p.N - n0);   // channels left
+  const bool vecd = FORM == 0 ? p.vec_n : p.vec_c, vecg = FORM == 0 ? p.vec_c : p.vec_n;
+  const int ntaps = p.k * p.k * p.k;
+  const int HV = p.hz * p.hy * p.hx;
+  const int tx = 1 << p.lx, ty = 1 << p.ly;
+
+  f32x16_t acc[MAXT][TN][TC];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
+
+  // lane roles for the transposed reads
+  const int g16 = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int chan_b = ((g16 & 1) * 16 + 4 * pp) * 2;   // byte offset of this lane's 4 channels in a 32-channel block
+  const int vrow = 8 * (g16 >> 1) + q;                // voxel (within a 16-voxel K step) whose row this lane addresses
+
+  const int tile_begin = blockIdx.x * p.tiles_per_block;
+  int tile_end = tile_begin + p.tiles_per_block;
+  if (tile_end > p.tiles_total) tile_end = p.tiles_total;
+
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int tix = tile % p.ntx, tiy = (tile / p.ntx) % p.nty, tiz = tile / (p.ntx * p.nty);
+    const int x0 = tix << p.lx, y0 = tiy << p.ly, z0 = tiz << p.lz;
+    __syncthreads();   // previous tile's reads are done
+    // ---- dense tile ----
+    for (int piece = tid; piece < TM * (CDB / 8); piece += 256) {
+      const int row = piece / (CDB / 8), ch = piece % (CDB / 8);
+      const int vx = row & (tx - 1), vy = (row >> p.lx) & (ty - 1), vz = row >> (p.lx + p.ly);
+      const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (gz < p.Mz && gy < p.My && gx < p.Mx && ch * 8 < chd)
+        v = load8(dense + (long)((gz * p.My + gy) * p.Mx + gx) * ldd + ch * 8, chd - ch * 8, vecd);
+      *reinterpret_cast<uint4*>(Dt + row * PD + ch * 16) = v;
+    }
+    // ---- gathered halo ----
+    const int bz = z0 * p.stride - p.pad, by = y0 * p.stride - p.pad, bx = x0 * p.stride - p.pad;
+    for (int piece = tid; piece < HV * (CGB / 8); piece += 256) {
+      const int row = piece / (CGB / 8), ch = piece % (CGB / 8);
+      const int hxi = row % p.hx, hyi = (row / p.hx) % p.hy, hzi = row / (p.hx * p.hy);
+      const int gz = bz + hzi, gy = by + hyi, gx = bx + hxi;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((unsigned)gz < (unsigned)p.Gz && (unsigned)gy < (unsigned)p.Gy && (unsigned)gx < (unsigned)p.Gx && ch * 8 < chg)
+        v = load8(gath + (long)((gz * p.Gy + gy) * p.Gx + gx) * ldg + ch * 8, chg - ch * 8, vecg);
+      *reinterpret_cast<uint4*>(Gt + row * PG + ch * 16) = v;
+    }
+    __syncthreads();
+    // ---- MFMA over the tile's voxels, 16 per K step ----
+    const int ksteps = TM >> 4;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      if (p.k == 1 && (ks & 3) != wid) continue;     // 1x1x1: the 4 waves share the single tap by K step
+      const int v1 = ks * 16 + vrow, v2 = v1 + 4;
+      const int x1 = v1 & (tx - 1), y1 = (v1 >> p.lx) & (ty - 1), z1 = v1 >> (p.lx + p.ly);
+      const int x2 = v2 & (tx - 1), y2 = (v2 >> p.lx) & (ty - 1), z2 = v2 >> (p.lx + p.ly);
+      const int d1 = v1 * PD + chan_b, d2 = v2 * PD + chan_b;
+      const int g1 = ((z1 * p.stride * p.hy + y1 * p.stride) * p.hx + x1 * p.stride) * PG + chan_b;
+      const int g2 = ((z2 * p.stride * p.hy + y2 * p.stride) * p.hx + x2 * p.stride) * PG + chan_b;
+      constexpr int TD = FORM == 0 ? TN : TC, TG = FORM == 0 ? TC : TN;
+      bf16x8_t df[TD];
+#pragma unroll
+      for (int i = 0; i < TD; ++i) {
+        const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(Dt + d1 + i * 64));
+        const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(Dt + d2 + i * 64));
+        df[i] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int tap = p.k == 1 ? (t == 0 ? 0 : ntaps) : wid + 4 * t;
+        if (tap < ntaps) {
+          const int kx = tap % p.k, ky = (tap / p.k) % p.k, kz = tap / (p.k * p.k);
+          const int toff = ((kz * p.hy + ky) * p.hx + kx) * PG;
+          bf16x8_t gf[TG];
+#pragma unroll
+          for (int j = 0; j < TG; ++j) {
+            const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(Gt + g1 + toff + j * 64));
+            const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(Gt + g2 + toff + j * 64));
+            gf[j] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TC; ++j) {
+              if (FORM == 0) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], gf[j], acc[t][i][j], 0, 0, 0);
+              else acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], df[j], acc[t][i][j], 0, 0, 0);
+            }
+        }
+      }
+    }
+  }
+  // ---- merge into dwk[b][tap][n][c] ----
+  float* wout = p.dwk + (long)b * p.wsb;
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int tap = p.k == 1 ? (t == 0 ? 0 : ntaps) : wid + 4 * t;
+    if (tap < ntaps) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int n = n0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            const int c = c0 + j * 32 + fr;
+            if (n < p.N && c < p.C) atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, acc[t][i][j][e]);
+          }
+    }
+  }
+}
+
+static int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+struct WgradPlan { WgradP2 p; int TM; size_t lds; int tn, tc; dim3 grid; bool ok; };
+
+static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  WgradPlan pl{};
+  pl.ok = false;
+  if (x->dtype != COMA_BF16 || dy->dtype != COMA_BF16) return pl;
+  if (d->ksize != 3 && d->ksize != 1) return pl;
+  if ((long)t_vox(x) * x->ld >= (1L << 31) || (long)t_vox(dy) * dy->ld >= (1L << 31)) return pl;
+  if (d->form == 1 && d->stride != 2) return pl;
+  WgradP2& p = pl.p;
+  p.dyp = (const bf16_t*)dy->data; p.ldn = (int)dy->ld; p.sbn = dy->sb;
+  p.xp = (const bf16_t*)x->data; p.ldc = (int)x->ld; p.sbc = x->sb;
+  p.N = dy->C; p.C = x->C;
+  const coma_tensor* dn = d->form == 0 ? dy : x;     // dense
+  const coma_tensor* ga = d->form == 0 ? x : dy;     // gathered
+  p.Mz = dn->D; p.My = dn->H; p.Mx = dn->W; p.Gz = ga->D; p.Gy = ga->H; p.Gx = ga->W;
+  p.k = d->ksize; p.stride = d->stride; p.pad = d->pad;
+  p.vec_n = dy->ld % 8 == 0 && dy->sb % 8 == 0 && (!dy->data || aligned16(dy->data));
+  p.vec_c = x->ld % 8 == 0 && x->sb % 8 == 0 && (!x->data || aligned16(x->data));
+  pl.tn = (dy->C > 32 && !(x->C > 32 && x->C > dy->C)) ? 2 : 1;
+  pl.tc = (pl.tn == 1 && x->C > 32) ? 2 : 1;
+  // tile: up to 256 dense voxels at stride 1, 64 at stride 2 (the halo grows 8x)
+  const int budget = d->stride == 1 ? 8 : 6;            // log2 voxels
+  int lx = ilog2_ceil(p.Mx); if (lx > 5) lx = 5; if (lx < 4 && budget - lx > ilog2_ceil(p.My) + ilog2_ceil(p.Mz)) {}
+  if (d->stride == 2 && lx > 4) lx = 4;
+  int rem = budget - lx;
+  int ly = ilog2_ceil(p.My); if (ly > (rem + 1) / 2) ly = (rem + 1) / 2;
+  rem -= ly;
+  int lz = ilog2_ceil(p.Mz); if (lz > rem) lz = rem;
+  rem -= lz;
+  // leftover budget (small grids): keep the tile at least 16 voxels
+  while (lx + ly + lz < 4) ++lx;
+  p.lx = lx; p.ly = ly; p.lz = lz;
+  pl.TM = 1 << (lx + ly + lz);
+  p.hz = ((1 << lz) - 1) * p.stride + p.k; p.hy = ((1 << ly) - 1) * p.stride + p.k; p.hx = ((1 << lx) - 1) * p.stride + p.k;
+  p.ntx = (p.Mx + (1 << lx) - 1) >> lx; p.nty = (p.My + (1 << ly) - 1) >> ly; p.ntz = (p.Mz + (1 << lz) - 1) >> lz;
+  p.tiles_total = p.ntx * p.nty * p.ntz;
+  const int cdb = 32 * (d->form == 0 ? pl.tn : pl.tc), cgb = 32 * (d->form == 0 ? pl.tc : pl.tn);
+  pl.lds = (size_t)pl.TM * cdb * 2 + (size_t)p.hz * p.hy * p.hx * cgb * 2;
+  if (pl.lds > 160 * 1024) return pl;
+  p.cblocks = (p.C + 32 * pl.tc - 1) / (32 * pl.tc);
+  const int pairs = ((p.N + 32 * pl.tn - 1) / (32 * pl.tn)) * p.cblocks;
+  // aim for ~1024 blocks in total
+  int chunks = 1024 / (pairs * x->B);
+  if (chunks < 1) chunks = 1;
+  if (chunks > p.tiles_total) chunks = p.tiles_total;
+  p.tiles_per_block = (p.tiles_total + chunks - 1) / chunks;
+  chunks = (p.tiles_total + p.tiles_per_block - 1) / p.tiles_per_block;
+  pl.grid = dim3((unsigned)chunks, (unsigned)pairs, (unsigned)x->B);
+  const long taps = (long)d->ksize * d->ksize * d->ksize;
+  p.wsb = d->per_sample_w ? taps * p.N * p.C : 0;
+  pl.ok = true;
+  return pl;
+}
+
+bool conv_mfma_wgrad_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  return wgrad_plan(d, x, dy).ok;
+}
 size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc*, const coma_tensor*, const coma_tensor*) { return 0; }
-int conv_mfma_wgrad(const coma_conv_desc*, const coma_tensor*, const coma_tensor*, float*, void*, size_t, hipStream_t) {
-  coma_set_error("MFMA wgrad not built"); return 3; }
+
+int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void*, size_t,
+                    hipStream_t s) {
+  WgradPlan pl = wgrad_plan(d, x, dy);
+  COMA_CHECK(pl.ok, "conv_mfma_wgrad: unsupported problem");
+  pl.p.dwk = dwk;
+  const long wsz = (long)d->ksize * d->ksize * d->ksize * dy->C * x->C * (d->per_sample_w ? x->B : 1);
+  if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+#define WL(TNV, TCV, F)                                                                                          \
+  do {                                                                                                           \
+    hipFuncSetAttribute((const void*)conv_mfma_wgrad_k<TNV, TCV, F>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        160 * 1024);                                                                             \
+    hipLaunchKernelGGL((conv_mfma_wgrad_k<TNV, TCV, F>), pl.grid, dim3(256), pl.lds, s, pl.p);                   \
+  } while (0)
+  if (d->form == 0) {
+    if (pl.tn == 2) WL(2, 1, 0); else if (pl.tc == 2) WL(1, 2, 0); else WL(1, 1, 0);
+  } else {
+    if (pl.tn == 2) WL(2, 1, 1); else if (pl.tc == 2) WL(1, 2, 1); else WL(1, 1, 1);
+  }
+#undef WL
+  COMA_LAUNCH_CHECK();
+  return 0;
+}

@@ -73,12 +73,21 @@ __global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double2* partial
   }
 }
 
-__global__ void stats_finalize_k(const double2* partial, int nchunks, int G, int C, int64_t R, float eps,
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one wave per (group, channel): lanes stride over the chunk partials, fixed-order butterfly
+__global__ __launch_bounds__(256) void stats_finalize_k(const double2* partial, int nchunks, int G, int C, int64_t R, float eps,
                                  float* mean, float* rstd, float* rmean, float* rvar, float momentum) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= G * C) return;
   double s = 0.0, q = 0.0;
-  for (int k = 0; k < nchunks; ++k) { const double2 v = partial[(int64_t)k * G * C + i]; s += v.x; q += v.y; }
+  for (int k = lane; k < nchunks; k += 64) { const double2 v = partial[(int64_t)k * G * C + i]; s += v.x; q += v.y; }
+  s = wave_sum(s); q = wave_sum(q);
+  if (lane != 0) return;
   const double m = s / (double)R;
   double var = q / (double)R - m * m;
   if (var < 0.0) var = 0.0;
@@ -180,33 +189,39 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
   }
 }
 
-// reduce chunks -> sums[G][C][2] (fp32: mean dz, mean dz*xhat), dgamma/dbeta[C], dslope
-__global__ void norm_bwd_finalize_k(const double* partial, int nchunks, int G, int C, int64_t R, float* sums,
-                                    float* dgamma, float* dbeta, float* dslope) {
+// stage 1: one wave per (g,c) reduces the chunk partials -> tot[(g*C+c)*3 .. +3] (fp64) and the fp32 means
+__global__ __launch_bounds__(256) void norm_bwd_reduce_k(const double* partial, int nchunks, int G, int C, int64_t R,
+                                                         double* tot, float* sums) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= G * C) return;
+  double a = 0.0, b = 0.0, s = 0.0;
+  for (int k = lane; k < nchunks; k += 64) {
+    const double* v = partial + ((int64_t)k * G * C + i) * 3;
+    a += v[0]; b += v[1]; s += v[2];
+  }
+  a = wave_sum(a); b = wave_sum(b); s = wave_sum(s);
+  if (lane == 0) {
+    tot[i * 3] = a; tot[i * 3 + 1] = b; tot[i * 3 + 2] = s;
+    sums[i * 2] = (float)(a / (double)R);
+    sums[i * 2 + 1] = (float)(b / (double)R);
+  }
+}
+// stage 2: dgamma/dbeta[c] = sum over groups, dslope = sum over everything (<= 1024 numbers)
+__global__ __launch_bounds__(256) void norm_bwd_finalize_k(const double* tot, int G, int C, float* dgamma, float* dbeta,
+                                                           float* dslope) {
   __shared__ double ssl[256];
   double sl = 0.0;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int c = threadIdx.x; c < C; c += 256) {
     double dg = 0.0, db = 0.0;
-    for (int g = 0; g < G; ++g) {
-      double a = 0.0, b = 0.0, s = 0.0;
-      for (int k = 0; k < nchunks; ++k) {
-        const double* v = partial + (((int64_t)k * G + g) * C + c) * 3;
-        a += v[0]; b += v[1]; s += v[2];
-      }
-      sums[(g * C + c) * 2] = (float)(a / (double)R);
-      sums[(g * C + c) * 2 + 1] = (float)(b / (double)R);
-      db += a; dg += b; sl += s;
-    }
+    for (int g = 0; g < G; ++g) { db += tot[(g * C + c) * 3]; dg += tot[(g * C + c) * 3 + 1]; sl += tot[(g * C + c) * 3 + 2]; }
     if (dgamma) dgamma[c] = (float)dg;
     if (dbeta) dbeta[c] = (float)db;
   }
   ssl[threadIdx.x] = sl;
   __syncthreads();
-  if (threadIdx.x == 0 && dslope) {
-    double t = 0.0;
-    for (int i = 0; i < (int)blockDim.x; ++i) t += ssl[i];
-    *dslope = (float)t;
-  }
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) ssl[threadIdx.x] += ssl[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0 && dslope) *dslope = (float)ssl[0];
 }
 
 template <typename T, int VEC>
@@ -239,19 +254,21 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p, const floa
 }
 
 // column sums of a [B][V][C] tensor -> fp32 out[B or 1][C]  (conv bias gradient, spatial mean)
-__global__ void colsum_finalize_k(const double2* partial, int nchunks, int G, int C, double scale, float* out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_finalize_k(const double2* partial, int nchunks, int G, int C, double scale, float* out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= G * C) return;
   double s = 0.0;
-  for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * G * C + i].x;
-  out[i] = (float)(s * scale);
+  for (int k = lane; k < nchunks; k += 64) s += partial[(int64_t)k * G * C + i].x;
+  s = wave_sum(s);
+  if (lane == 0) out[i] = (float)(s * scale);
 }
 
 static int pick_vec(const coma_tensor* x) { return t_vec(x, 4) >= 4 ? 4 : 1; }
 
 extern "C" size_t coma_norm_ws_bytes(const coma_tensor* x) {
   // partials: <= 1024 (chunk,group) pairs x C x 3 doubles, + sums [B][C][2] floats
-  return (size_t)1024 * x->C * 3 * sizeof(double) + (size_t)x->B * x->C * 2 * sizeof(float) + 256;
+  return (size_t)1024 * x->C * 3 * sizeof(double) + (size_t)x->B * x->C * (3 * sizeof(double) + 2 * sizeof(float)) + 256;
 }
 
 template <typename T>
@@ -280,7 +297,7 @@ extern "C" int coma_norm_stats(const coma_tensor* x, int32_t mode, float eps, fl
   RowsP p;
   if (int rc = run_partial(x, mode, p, ws, ws_bytes, s)) return rc;
   const int n = p.G * p.C;
-  hipLaunchKernelGGL(stats_finalize_k, dim3((n + 127) / 128), dim3(128), 0, s, (const double2*)ws, p.nchunks, p.G,
+  hipLaunchKernelGGL(stats_finalize_k, dim3((n + 3) / 4), dim3(256), 0, s, (const double2*)ws, p.nchunks, p.G,
                      p.C, p.R, eps, mean, rstd, running_mean, running_var, momentum);
   COMA_LAUNCH_CHECK();
   return 0;
@@ -291,7 +308,7 @@ extern "C" int coma_spatial_mean(const coma_tensor* x, float* out, void* ws, siz
   RowsP p;
   if (int rc = run_partial(x, COMA_NORM_INSTANCE, p, ws, ws_bytes, s)) return rc;
   const int n = p.G * p.C;
-  hipLaunchKernelGGL(colsum_finalize_k, dim3((n + 127) / 128), dim3(128), 0, s, (const double2*)ws, p.nchunks, p.G,
+  hipLaunchKernelGGL(colsum_finalize_k, dim3((n + 3) / 4), dim3(256), 0, s, (const double2*)ws, p.nchunks, p.G,
                      p.C, 1.0 / (double)p.R, out);
   COMA_LAUNCH_CHECK();
   return 0;
@@ -302,7 +319,7 @@ int colsum(const coma_tensor* x, int per_sample, float* out, void* ws, size_t ws
   RowsP p;
   if (int rc = run_partial(x, per_sample ? COMA_NORM_INSTANCE : COMA_NORM_BATCH, p, ws, ws_bytes, s)) return rc;
   const int n = p.G * p.C;
-  hipLaunchKernelGGL(colsum_finalize_k, dim3((n + 127) / 128), dim3(128), 0, s, (const double2*)ws, p.nchunks, p.G,
+  hipLaunchKernelGGL(colsum_finalize_k, dim3((n + 3) / 4), dim3(256), 0, s, (const double2*)ws, p.nchunks, p.G,
                      p.C, 1.0, out);
   COMA_LAUNCH_CHECK();
   return 0;
@@ -354,7 +371,8 @@ extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, in
   RowsP rp = make_rows(x, mode, vec);
   COMA_CHECK(rp.cv <= 256, "norm: C=%d too large", x->C);
   double* partial = (double*)ws;
-  float* sums = (float*)((char*)ws + (size_t)1024 * x->C * 3 * sizeof(double));
+  double* tot = (double*)((char*)ws + (size_t)1024 * x->C * 3 * sizeof(double));
+  float* sums = (float*)(tot + (size_t)x->B * x->C * 3);
   dim3 pg(rp.nchunks, rp.G);
 #define L(T, V) hipLaunchKernelGGL((norm_bwd_partial_k<T, V>), pg, dim3(256), 0, s, rp, dy->data, dy->ld, dy->sb, \
                                    mean, rstd, gamma, beta, act, slope, partial)
@@ -362,9 +380,13 @@ extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, in
   else { if (vec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
 #undef L
   COMA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_bwd_finalize_k, dim3(1), dim3(256), 0, s, partial, rp.nchunks, rp.G, rp.C, rp.R, sums,
-                     dgamma, dbeta, dslope);
+  hipLaunchKernelGGL(norm_bwd_reduce_k, dim3((rp.G * rp.C + 3) / 4), dim3(256), 0, s, partial, rp.nchunks, rp.G, rp.C,
+                     rp.R, tot, sums);
   COMA_LAUNCH_CHECK();
+  if (dgamma || dbeta || dslope) {
+    hipLaunchKernelGGL(norm_bwd_finalize_k, dim3(1), dim3(256), 0, s, tot, rp.G, rp.C, dgamma, dbeta, dslope);
+    COMA_LAUNCH_CHECK();
+  }
   ApplyP p = make_apply(x, dx, mode, vec);
   p.dy = dy->data; p.lddy = dy->ld; p.sbdy = dy->sb;
   p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.slope = slope; p.act = act;

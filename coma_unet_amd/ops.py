@@ -134,8 +134,8 @@ def conv_out_grid(shape, ksize, stride, transposed):
 def pick_algo(x_shape, x_dtype, n_out, ksize, stride, transposed, per_sample, device, algo=0):
     """(algo_fwd, algo_dgrad) the library resolves for this layer."""
     B, Do, Ho, Wo = conv_out_grid(x_shape, ksize, stride, transposed)
-    xt = L.Tensor(1, L.dtype_code(x_dtype), x_shape[0], x_shape[1], x_shape[2], x_shape[3], x_shape[4], x_shape[4], 0)
-    yt = L.Tensor(1, L.dtype_code(x_dtype), B, Do, Ho, Wo, n_out, n_out, 0)
+    xt = L.Tensor(None, L.dtype_code(x_dtype), x_shape[0], x_shape[1], x_shape[2], x_shape[3], x_shape[4], x_shape[4], 0)
+    yt = L.Tensor(None, L.dtype_code(x_dtype), B, Do, Ho, Wo, n_out, n_out, 0)
     form = 1 if transposed else 0
     a_f = lib.coma_conv_pick_algo(_desc(ksize, stride, form, per_sample, algo), xt, yt)
     a_d = lib.coma_conv_pick_algo(_desc(ksize, stride, 1 - form, per_sample, algo), yt, xt)

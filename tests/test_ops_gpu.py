@@ -288,3 +288,100 @@ def test_adamw_matches_torch():
         opt.step()
         ops.adamw_(p, gr.to(dev), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step)
     assert rel(p, pr) < 1e-6
+
+
+THIN_CASES = [
+    # cin, cout, k, stride, transposed, dims  (bf16 wgrad goes through the MFMA kernel with zero-padded channels)
+    (1, 32, 3, 1, False, (6, 9, 37)), (32, 1, 1, 1, False, (5, 8, 33)), (3, 16, 3, 1, False, (4, 6, 35)),
+    (16, 16, 3, 1, False, (4, 5, 18)), (16, 1, 3, 1, False, (5, 5, 17)), (2, 8, 3, 1, False, (3, 4, 40)),
+    (32, 16, 1, 1, False, (6, 7, 33)), (256, 128, 1, 1, False, (4, 4, 4)), (2, 1, 1, 1, False, (4, 4, 20)),
+    (48, 40, 3, 1, False, (3, 5, 9)),
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_thin_conv_bf16_auto_algo(case):
+    """Thin / 1x1x1 layers in bf16 with algo=auto: whichever kernels the library picks must agree with fp64."""
+    ops, L = _ops()
+    cin, cout, k, s, tr, dims = case
+    B = 2
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn((B, cin, *dims), generator=g).bfloat16().double()
+    w = (torch.randn((cout, cin, k, k, k), generator=g) * 0.2).bfloat16().double()
+    bias = torch.randn((cout,), generator=g).double()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, bias, stride=s, padding=(k - 1) // 2)
+    gy = torch.randn(yr.shape, generator=g).bfloat16().double()
+    yr.backward(gy)
+    dev = "cuda"
+    xi = to_int(x).to(dev, torch.bfloat16).requires_grad_(True)
+    mg = w.float().to(dev).requires_grad_(True)
+    a_f, a_d = ops.pick_algo(xi.shape, xi.dtype, cout, k, s, tr, False, xi.device)
+    wd = lambda a: torch.bfloat16 if a == 2 else torch.float32
+    wk_f, wk_d = ops.PrepWeights.apply(mg, None, tr, wd(a_f), wd(a_d))
+    y = ops.Conv.apply(xi, wk_f, wk_d, bias.float().to(dev), k, s, tr, False, 0, None)
+    assert rel(to_ext(y), yr) < 8e-3
+    y.backward(to_int(gy).to(dev, torch.bfloat16))
+    assert rel(to_ext(xi.grad), xr.grad) < 8e-3
+    assert rel(mg.grad, wr.grad) < 8e-3
+
+
+MFMA_CASES = [
+    # cin, cout, k, stride, transposed, dims
+    (32, 32, 3, 1, False, (6, 9, 37)), (64, 32, 3, 1, False, (5, 8, 33)), (32, 64, 3, 2, False, (8, 10, 36)),
+    (64, 32, 3, 2, True, (4, 5, 17)), (128, 128, 3, 1, False, (4, 4, 8)), (256, 128, 3, 2, True, (2, 3, 4)),
+    (32, 64, 1, 1, False, (5, 6, 7)), (64, 64, 3, 1, False, (3, 3, 3)), (32, 32, 3, 2, False, (7, 9, 11)),
+]
+
+
+@pytest.mark.parametrize("per_sample", [False, True])
+@pytest.mark.parametrize("case", MFMA_CASES)
+def test_conv_mfma_fwd_dgrad_wgrad(case, per_sample):
+    """bf16 MFMA implicit-GEMM path (algo=2) against an fp64 reference on bf16-exact operands;
+    outputs are rounded to bf16 once (2^-9 relative), accumulation is fp32."""
+    ops, L = _ops()
+    cin, cout, k, s, tr, dims = case
+    B, E = 2, 3
+    g = torch.Generator().manual_seed(sum(dims) + cin)
+    x = (torch.randn((B, cin, *dims), generator=g) * 1.0).bfloat16().double()
+    wshape = (cin, cout, k, k, k) if tr else (cout, cin, k, k, k)
+    p = (k - 1) // 2
+    if per_sample:
+        master = torch.randn((E, *wshape), generator=g) * 0.1
+        r = torch.rand((B, E), generator=g)
+        wmix = torch.einsum("be,e...->b...", r.double(), master.double()).float().bfloat16().double()
+        bias = torch.randn((B, cout), generator=g)
+    else:
+        master = (torch.randn(wshape, generator=g) * 0.1).bfloat16().float()
+        r = None
+        wmix = master.double().unsqueeze(0).expand(B, *wshape)
+        bias = torch.randn((cout,), generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = wmix.clone().requires_grad_(True)
+
+    def ref_conv(xb, w, b):
+        if tr:
+            return F.conv_transpose3d(xb, w, b, stride=s, padding=p, output_padding=s - 1)
+        return F.conv3d(xb, w, b, stride=s, padding=p)
+
+    yr = torch.cat([ref_conv(xr[i:i + 1], wr[i], (bias[i] if per_sample else bias).double()) for i in range(B)], 0)
+    gy = torch.randn(yr.shape, generator=g).bfloat16().double()
+    yr.backward(gy)
+    dev = "cuda"
+    xi = to_int(x).to(dev, torch.bfloat16).requires_grad_(True)
+    mg = master.to(dev).requires_grad_(True)
+    rg = r.to(dev) if per_sample else None
+    wk_f, wk_d = ops.PrepWeights.apply(mg, rg, tr, torch.bfloat16, torch.bfloat16)
+    y = ops.Conv.apply(xi, wk_f, wk_d, bias.to(dev), k, s, tr, per_sample, 2, None)
+    assert rel(to_ext(y), yr) < 5e-3
+    wk_f.retain_grad()
+    y.backward(to_int(gy).to(dev, torch.bfloat16))
+    assert rel(to_ext(xi.grad), xr.grad) < 5e-3
+    # kernel-layout weight gradient [Bw, taps, cout, cin] vs reference per-sample weight gradient
+    gw = wr.grad    # (B, *wshape)
+    if tr:
+        gw = gw.permute(0, 2, 1, 3, 4, 5)
+    gw = gw.reshape(B, cout, cin, k ** 3).permute(0, 3, 1, 2)
+    if not per_sample:
+        gw = gw.sum(0, keepdim=True)
+    assert rel(wk_f.grad, gw) < 5e-3
