@@ -25,6 +25,27 @@ struct GatherP {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 2) | (chunk ^ ((row >> 2) & 3)); }  // 16-B slot index
 
+// blockIdx -> work-item remap: the dispatcher deals consecutive blocks round-robin over the 8 XCDs
+// (each with a private 4 MiB L2); give every XCD one CONTIGUOUS range of the work so that
+// neighbouring tiles (which share halo voxels) hit in the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+// tile id -> (tix, tiy, tiz): x slowest, then blocks of 8 z-tiles, then y, z-in-block fastest, so
+// the ~64 tiles an XCD works on at once form an 8(y) x 8(z) patch (halo overlap 3.2x -> ~1.3x).
+// ids run over ntx * ceil(ntz/8) * nty * 8; returns false for the padding ids (tiz >= ntz).
+__device__ __forceinline__ bool tile_coords(int id, int ntx, int nty, int ntz, int& tix, int& tiy, int& tiz) {
+  const int ntzb = (ntz + 7) >> 3;
+  const int zin = id & 7;
+  int t = id >> 3;
+  tiy = t % nty; t /= nty;
+  const int tzb = t % ntzb;
+  tix = t / ntzb;
+  tiz = tzb * 8 + zin;
+  return tiz < ntz && tix < ntx;
+}
+
 // MODE 0: in = m*stride - pad + tap  (all taps; `flip` mirrors the weight tap index)
 // MODE 1: stride-2 transposed gather, one output-parity class per blockIdx.y slice
 template <int BN, int MODE>
@@ -86,17 +107,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
   const int nsteps = ntaps * cchunks;
 
   uint4 ra[A_PIECES], rb[B_PIECES];
-  auto load_step = [&](int step) {
-    const int t = step / cchunks, cc = step - t * cchunks;
+  // K-step counters advanced incrementally (no integer division in the loop)
+  int l_t = 0, l_cc = 0, l_jx = 0, l_jy = 0, l_jz = 0;
+  const int l_nx = MODE == 0 ? p.k : 1 + px, l_ny = MODE == 0 ? p.k : 1 + py;
+  auto load_step = [&](int) {
+    const int t = l_t, cc = l_cc;
     int dz, dy, dx, wtap;
     if (MODE == 0) {
-      const int kx = t % p.k, ky = (t / p.k) % p.k, kz = t / (p.k * p.k);
-      dz = kz; dy = ky; dx = kx;
+      dz = l_jz; dy = l_jy; dx = l_jx;
       wtap = p.flip ? (ntaps - 1 - t) : t;
     } else {
       // per dim: parity 0 -> tap 1, delta 0 ; parity 1 -> j=0: tap 0, delta +1 ; j=1: tap 2, delta 0
-      const int nx = 1 + px, ny = 1 + py;
-      const int jx = t % nx, jy = (t / nx) % ny, jz = t / (nx * ny);
+      const int jx = l_jx, jy = l_jy, jz = l_jz;
       const int tx = px ? (jx ? 2 : 0) : 1, ty = py ? (jy ? 2 : 0) : 1, tz = pz ? (jz ? 2 : 0) : 1;
       dx = px ? (jx ? 0 : 1) : 0; dy = py ? (jy ? 0 : 1) : 0; dz = pz ? (jz ? 0 : 1) : 0;
       wtap = (tz * 3 + ty) * 3 + tx;
@@ -115,6 +137,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
       const int n = piece >> 2;
       rb[i] = make_uint4(0, 0, 0, 0);
       if (n < BN) rb[i] = *reinterpret_cast<const uint4*>(wb + ((long)wtap * p.N + n0 + n) * p.C + c0);
+    }
+    // advance (cc fastest, then x, y, z of the tap)
+    if (++l_cc == cchunks) {
+      l_cc = 0; ++l_t;
+      if (++l_jx == l_nx) { l_jx = 0; if (++l_jy == l_ny) { l_jy = 0; ++l_jz; } }
     }
   };
   auto store_step = [&](int buf) {
@@ -187,10 +214,193 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
   }
 }
 
+// 8 channels starting at `ptr`, of which `nvalid` exist; `vec` = 16-byte access is legal
+__device__ __forceinline__ uint4 load8(const bf16_t* ptr, int nvalid, bool vec) {
+  if (vec && nvalid >= 8) return *reinterpret_cast<const uint4*>(ptr);
+  unsigned short e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = j < nvalid ? reinterpret_cast<const unsigned short*>(ptr)[j] : (unsigned short)0;
+  return make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                    e[6] | ((unsigned)e[7] << 16));
+}
+
+// =====================================================================================
+// Stride-1 3x3x3 convolution (forward, and data-gradient via `flip`) with the input HALO
+// staged once per channel chunk in LDS: a block owns 8 M-tiles (2 z-planes x 4 row groups of
+// 32 voxels) = 256 output voxels x 32 output channels; each of the 27 taps re-reads the same
+// LDS halo at a shifted voxel address, so the 27-fold input reuse never leaves the CU.  The
+// weights of the current chunk stream through LDS one kz-plane (9 taps) at a time.
+// CK = channels per chunk (32, or 16 for the thin full-resolution layers so that an MFMA K step
+// is exactly one tap).  Rows are XOR-swizzled so every ds_read_b128 fragment read is
+// bank-conflict free; ~70 KB LDS => 2 blocks (8 waves) per CU overlap staging with MFMA.
+// =====================================================================================
+struct HaloP {
+  const bf16_t* x; int ldx; long sbx; int D, H, W, C;
+  bf16_t* y; int ldy; long sby; int N;
+  const bf16_t* w; long wsb;
+  const float* bias; int bsb;
+  int flip, vecx, vecw;
+  int ntx, nty, ntz;
+};
+
+template <int CK> __device__ __forceinline__ int hswz(int row, int chunk) {
+  // 16-byte slot index of (row, chunk) in a [rows][CK] bf16 image
+  if (CK == 32) return (row << 2) | (chunk ^ ((row >> 2) & 3));
+  return (row << 1) | (chunk ^ ((row >> 3) & 1));
+}
+
+template <int CK, int LX, int VEC>   // VEC=1: every 8-channel piece is a legal, fully valid 16-byte load
+__global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
+  constexpr int TX = 1 << LX, RY = 32 / TX;      // M-tile = RY rows of TX voxels
+  constexpr int TY = 4 * RY, TZ = 2;
+  constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
+  constexpr int CPR = CK / 8;                     // 16-byte chunks per row
+  constexpr int KS = CK / 16;                     // MFMA K steps per tap
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* Hl = reinterpret_cast<uint4*>(smem);                  // halo  [HV][CPR]
+  uint4* Wl = Hl + HV * CPR;                                   // weights [9][32][CPR]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.z, n0 = blockIdx.y * 32;
+  int tix, tiy, tiz;
+  if (!tile_coords(xcd_remap(blockIdx.x, gridDim.x), p.ntx, p.nty, p.ntz, tix, tiy, tiz)) return;
+  const int x0 = tix * TX, y0 = tiy * TY, z0 = tiz * TZ;
+  const bf16_t* xb = p.x + (long)b * p.sbx;
+  const bf16_t* wb = p.w + (long)b * p.wsb;
+  const int fr = lane & 31, fh = lane >> 5;
+
+  f32x16_t acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // halo voxel (tap 0,0,0 corner) of this lane's row in each of the wave's two M-tiles
+  int hbase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = wid * 2 + i;                    // M-tile: z = j >> 2, row group = j & 3
+    const int zz = j >> 2, yy = (j & 3) * RY + (fr >> LX), xx = fr & (TX - 1);
+    hbase[i] = (zz * HY + yy) * HX + xx;
+  }
+
+  // ---- staging with register prefetch: all loads of a phase are issued before any is consumed ----
+  constexpr int HP = HV * CPR, HIT = (HP + 255) / 256;          // halo pieces, per-thread iterations
+  constexpr int WP = 9 * 32 * CPR, WIT = (WP + 255) / 256;      // weight pieces of one kz-plane
+  uint4 hreg[HIT], wreg[WIT];
+  auto load_halo = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      const int piece = tid + 256 * it;
+      const int row = piece / CPR, ch = piece % CPR;
+      const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      const int cbeg = c0 + ch * 8;
+      hreg[it] = make_uint4(0, 0, 0, 0);
+      if (piece < HP && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W &&
+          cbeg < p.C)
+      {
+        const bf16_t* src = xb + (long)((gz * p.H + gy) * p.W + gx) * p.ldx + cbeg;
+        hreg[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8(src, p.C - cbeg, p.vecx);
+      }
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      const int piece = tid + 256 * it;
+      if (piece < HP) Hl[hswz<CK>(piece / CPR, piece % CPR)] = hreg[it];
+    }
+  };
+  auto load_w = [&](int c0, int g) {
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int piece = tid + 256 * it;
+      const int ch = piece % CPR, n = (piece / CPR) & 31, t9 = piece / (CPR * 32);
+      const int gt = g * 9 + t9;
+      const int wt = p.flip ? 26 - gt : gt;
+      const int cbeg = c0 + ch * 8;
+      wreg[it] = make_uint4(0, 0, 0, 0);
+      if (piece < WP && n0 + n < p.N && cbeg < p.C)
+      {
+        const bf16_t* src = wb + ((long)wt * p.N + n0 + n) * p.C + cbeg;
+        wreg[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8(src, p.C - cbeg, p.vecw);
+      }
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int piece = tid + 256 * it;
+      if (piece < WP) Wl[hswz<CK>((piece / (CPR * 32)) * 32 + ((piece / CPR) & 31), piece % CPR)] = wreg[it];
+    }
+  };
+
+  const int nchunks = (p.C + CK - 1) / CK;
+  load_halo(0);
+  load_w(0, 0);
+  for (int cc = 0; cc < nchunks; ++cc) {
+    const int c0 = cc * CK;
+    __syncthreads();                 // every wave is done reading the previous chunk's LDS images
+    store_halo();
+#pragma unroll 1
+    for (int g = 0; g < 3; ++g) {
+      if (g > 0) __syncthreads();    // previous kz-plane's weights are no longer being read
+      store_w();
+      __syncthreads();
+      if (g < 2) load_w(c0, g + 1);
+      else if (cc + 1 < nchunks) { load_w(c0 + CK, 0); load_halo(c0 + CK); }
+#pragma unroll 1
+      for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int t9 = dy * 3 + dx;
+          const int toff = (g * HY + dy) * HX + dx;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const uint4 bv = Wl[hswz<CK>(t9 * 32 + fr, ks * 2 + fh)];
+            const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(&bv);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const uint4 av = Hl[hswz<CK>(hbase[i] + toff, ks * 2 + fh)];
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&av), bf, acc[i], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue ----
+  const int n = n0 + fr;
+  if (n < p.N) {
+    const float bv = p.bias ? p.bias[b * p.bsb + n] : 0.f;
+    bf16_t* yb = p.y + (long)b * p.sby;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = wid * 2 + i;
+      const int gz = z0 + (j >> 2);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int gy = y0 + (j & 3) * RY + (row >> LX), gx = x0 + (row & (TX - 1));
+        if (gz < p.D && gy < p.H && gx < p.W)
+          yb[(long)((gz * p.H + gy) * p.W + gx) * p.ldy + n] = static_cast<bf16_t>(acc[i][e] + bv);
+      }
+    }
+  }
+}
+
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static bool halo_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  // stride-1 3x3x3 (either gather form); any channel counts; rows wide enough to fill 32-voxel M-tiles
+  return d->ksize == 3 && d->stride == 1 && x->W >= 8 && (long)x->H * x->W >= 32 &&
+         (x->C >= 8 || y->C >= 8 || x->C * y->C >= 8);
+}
 
 bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (x->dtype != COMA_BF16 || y->dtype != COMA_BF16) return false;
+  if ((long)t_vox(x) * x->ld >= (1L << 31) || (long)t_vox(y) * y->ld >= (1L << 31)) return false;
+  if (halo_ok(d, x, y)) return true;
   if (x->C % 32 || y->C % 32) return false;
   if (x->ld % 8 || y->ld % 8 || x->sb % 8 || y->sb % 8) return false;
   if (x->data && !aligned16(x->data)) return false;
@@ -211,8 +421,52 @@ static int launch_gather(const GatherP& p, int mode, int B, hipStream_t s) {
   return 0;
 }
 
+template <int CK, int LX, int VEC>
+static int launch_halo(const HaloP& p0, int B, hipStream_t s) {
+  HaloP p = p0;
+  constexpr int TX = 1 << LX, RY = 32 / TX, TY = 4 * RY, TZ = 2;
+  constexpr int HV = (TX + 2) * (TY + 2) * (TZ + 2);
+  p.ntx = (p.W + TX - 1) / TX; p.nty = (p.H + TY - 1) / TY; p.ntz = (p.D + TZ - 1) / TZ;
+  const size_t lds = (size_t)(HV + 9 * 32) * CK * 2;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)conv_mfma_halo_k<CK, LX, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+  dim3 grid((unsigned)(p.ntx * p.nty * ((p.ntz + 7) / 8) * 8), (unsigned)((p.N + 31) / 32), (unsigned)B);
+  hipLaunchKernelGGL((conv_mfma_halo_k<CK, LX, VEC>), grid, dim3(256), lds, s, p);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
+static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
+                          const coma_tensor* y, hipStream_t s) {
+  HaloP p;
+  p.x = (const bf16_t*)x->data; p.ldx = (int)x->ld; p.sbx = x->sb; p.D = x->D; p.H = x->H; p.W = x->W; p.C = x->C;
+  p.y = (bf16_t*)y->data; p.ldy = (int)y->ld; p.sby = y->sb; p.N = y->C;
+  p.w = (const bf16_t*)wk; p.wsb = d->per_sample_w ? 27L * y->C * x->C : 0;
+  p.bias = bias; p.bsb = d->per_sample_w ? y->C : 0;
+  p.flip = d->form == 1;
+  p.vecx = x->ld % 8 == 0 && x->sb % 8 == 0 && aligned16(x->data);
+  p.vecw = x->C % 8 == 0 && aligned16(wk);
+  const bool thin = x->C <= 16;
+  const int lx = x->W >= 32 ? 5 : (x->W >= 16 ? 4 : 3);
+  if (thin) {
+    if (lx == 5) return launch_halo<16, 5, 0>(p, x->B, s);
+    if (lx == 4) return launch_halo<16, 4, 0>(p, x->B, s);
+    return launch_halo<16, 3, 0>(p, x->B, s);
+  }
+  const bool vec = p.vecx && p.vecw && x->C % 32 == 0;
+  if (vec) {
+    if (lx == 5) return launch_halo<32, 5, 1>(p, x->B, s);
+    if (lx == 4) return launch_halo<32, 4, 1>(p, x->B, s);
+    return launch_halo<32, 3, 1>(p, x->B, s);
+  }
+  if (lx == 5) return launch_halo<32, 5, 0>(p, x->B, s);
+  if (lx == 4) return launch_halo<32, 4, 0>(p, x->B, s);
+  return launch_halo<32, 3, 0>(p, x->B, s);
+}
+
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                   const coma_tensor* y, hipStream_t s) {
+  if (halo_ok(d, x, y)) return conv_mfma_halo(d, x, wk, bias, y, s);
   COMA_CHECK(aligned16(wk) && aligned16(x->data), "conv_mfma: operands must be 16-byte aligned");
   GatherP p;
   p.x = (const bf16_t*)x->data; p.ldx = (int)x->ld; p.sbx = x->sb; p.Di = x->D; p.Hi = x->H; p.Wi = x->W; p.C = x->C;
@@ -264,17 +518,8 @@ struct WgradP2 {
   float* dwk; long wsb;
   int cblocks;         // ceil(C / (32*TC))
   int vec_n, vec_c;    // 16-byte loads legal on dy / x
+  unsigned m_hx, m_hxy; // magic multipliers: n / hx == umulhi(n, m_hx), n / (hx*hy) == umulhi(n, m_hxy)
 };
-
-// 8 channels starting at `ptr`, of which `nvalid` exist; `vec` = 16-byte access is legal
-__device__ __forceinline__ uint4 load8(const bf16_t* ptr, int nvalid, bool vec) {
-  if (vec && nvalid >= 8) return *reinterpret_cast<const uint4*>(ptr);
-  unsigned short e[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) e[j] = j < nvalid ? reinterpret_cast<const unsigned short*>(ptr)[j] : (unsigned short)0;
-  return make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
-                    e[6] | ((unsigned)e[7] << 16));
-}
 
 template <int TN, int TC, int FORM>
 __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
@@ -309,39 +554,62 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
 
+  // per-wave tap list (wave-uniform; hoisted out of every loop: no integer division inside)
+  int tap_w[MAXT], toff_w[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int tap = p.k == 1 ? (t == 0 ? 0 : ntaps) : wid + 4 * t;
+    tap_w[t] = tap;
+    const int kx = tap % p.k, ky = (tap / p.k) % p.k, kz = tap / (p.k * p.k);
+    toff_w[t] = ((kz * p.hy + ky) * p.hx + kx) * PG;
+  }
   // lane roles for the transposed reads
   const int g16 = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
   const int chan_b = ((g16 & 1) * 16 + 4 * pp) * 2;   // byte offset of this lane's 4 channels in a 32-channel block
   const int vrow = 8 * (g16 >> 1) + q;                // voxel (within a 16-voxel K step) whose row this lane addresses
 
-  const int tile_begin = blockIdx.x * p.tiles_per_block;
+  const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * p.tiles_per_block;
   int tile_end = tile_begin + p.tiles_per_block;
   if (tile_end > p.tiles_total) tile_end = p.tiles_total;
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
-    const int tix = tile % p.ntx, tiy = (tile / p.ntx) % p.nty, tiz = tile / (p.ntx * p.nty);
+    int tix, tiy, tiz;
+    if (!tile_coords(tile, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) continue;   // uniform across the block
     const int x0 = tix << p.lx, y0 = tiy << p.ly, z0 = tiz << p.lz;
     __syncthreads();   // previous tile's reads are done
-    // ---- dense tile ----
-    for (int piece = tid; piece < TM * (CDB / 8); piece += 256) {
-      const int row = piece / (CDB / 8), ch = piece % (CDB / 8);
-      const int vx = row & (tx - 1), vy = (row >> p.lx) & (ty - 1), vz = row >> (p.lx + p.ly);
-      const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (gz < p.Mz && gy < p.My && gx < p.Mx && ch * 8 < chd)
-        v = load8(dense + (long)((gz * p.My + gy) * p.Mx + gx) * ldd + ch * 8, chd - ch * 8, vecd);
-      *reinterpret_cast<uint4*>(Dt + row * PD + ch * 16) = v;
-    }
-    // ---- gathered halo ----
+    // ---- dense tile + gathered halo: loads are issued 8 deep before any is consumed ----
+    constexpr int U = 8;
     const int bz = z0 * p.stride - p.pad, by = y0 * p.stride - p.pad, bx = x0 * p.stride - p.pad;
-    for (int piece = tid; piece < HV * (CGB / 8); piece += 256) {
-      const int row = piece / (CGB / 8), ch = piece % (CGB / 8);
-      const int hxi = row % p.hx, hyi = (row / p.hx) % p.hy, hzi = row / (p.hx * p.hy);
-      const int gz = bz + hzi, gy = by + hyi, gx = bx + hxi;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if ((unsigned)gz < (unsigned)p.Gz && (unsigned)gy < (unsigned)p.Gy && (unsigned)gx < (unsigned)p.Gx && ch * 8 < chg)
-        v = load8(gath + (long)((gz * p.Gy + gy) * p.Gx + gx) * ldg + ch * 8, chg - ch * 8, vecg);
-      *reinterpret_cast<uint4*>(Gt + row * PG + ch * 16) = v;
+    const int ndp = TM * (CDB / 8), ngp = HV * (CGB / 8);
+    for (int base = tid; base < ndp + ngp; base += 256 * U) {
+      uint4 v[U];
+      int dst[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int piece = base + 256 * u;
+        v[u] = make_uint4(0, 0, 0, 0);
+        dst[u] = -1;
+        if (piece < ndp) {
+          const int row = piece / (CDB / 8), ch = piece % (CDB / 8);
+          const int vx = row & (tx - 1), vy = (row >> p.lx) & (ty - 1), vz = row >> (p.lx + p.ly);
+          const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+          dst[u] = row * PD + ch * 16;
+          if (gz < p.Mz && gy < p.My && gx < p.Mx && ch * 8 < chd)
+            v[u] = load8(dense + (long)((gz * p.My + gy) * p.Mx + gx) * ldd + ch * 8, chd - ch * 8, vecd);
+        } else if (piece < ndp + ngp) {
+          const int pg = piece - ndp;
+          const int row = pg / (CGB / 8), ch = pg % (CGB / 8);
+          const int q1 = (int)__umulhi((unsigned)row, p.m_hx), hzi = (int)__umulhi((unsigned)row, p.m_hxy);
+          const int hxi = row - q1 * p.hx, hyi = q1 - hzi * p.hy;
+          const int gz = bz + hzi, gy = by + hyi, gx = bx + hxi;
+          dst[u] = TM * PD + row * PG + ch * 16;
+          if ((unsigned)gz < (unsigned)p.Gz && (unsigned)gy < (unsigned)p.Gy && (unsigned)gx < (unsigned)p.Gx && ch * 8 < chg)
+            v[u] = load8(gath + (long)((gz * p.Gy + gy) * p.Gx + gx) * ldg + ch * 8, chg - ch * 8, vecg);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<uint4*>(smem + dst[u]) = v[u];
     }
     __syncthreads();
     // ---- MFMA over the tile's voxels, 16 per K step ----
@@ -364,10 +632,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
       }
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
-        const int tap = p.k == 1 ? (t == 0 ? 0 : ntaps) : wid + 4 * t;
-        if (tap < ntaps) {
-          const int kx = tap % p.k, ky = (tap / p.k) % p.k, kz = tap / (p.k * p.k);
-          const int toff = ((kz * p.hy + ky) * p.hx + kx) * PG;
+        if (tap_w[t] < ntaps) {
+          const int toff = toff_w[t];
           bf16x8_t gf[TG];
 #pragma unroll
           for (int j = 0; j < TG; ++j) {
@@ -391,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
   const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
-    const int tap = p.k == 1 ? (t == 0 ? 0 : ntaps) : wid + 4 * t;
+    const int tap = tap_w[t];
     if (tap < ntaps) {
 #pragma unroll
       for (int i = 0; i < TN; ++i)
@@ -445,10 +711,12 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   pl.TM = 1 << (lx + ly + lz);
   p.hz = ((1 << lz) - 1) * p.stride + p.k; p.hy = ((1 << ly) - 1) * p.stride + p.k; p.hx = ((1 << lx) - 1) * p.stride + p.k;
   p.ntx = (p.Mx + (1 << lx) - 1) >> lx; p.nty = (p.My + (1 << ly) - 1) >> ly; p.ntz = (p.Mz + (1 << lz) - 1) >> lz;
-  p.tiles_total = p.ntx * p.nty * p.ntz;
+  p.tiles_total = p.ntx * p.nty * ((p.ntz + 7) / 8) * 8;   // ids incl. z padding (tile_coords)
   const int cdb = 32 * (d->form == 0 ? pl.tn : pl.tc), cgb = 32 * (d->form == 0 ? pl.tc : pl.tn);
   pl.lds = (size_t)pl.TM * cdb * 2 + (size_t)p.hz * p.hy * p.hx * cgb * 2;
   if (pl.lds > 160 * 1024) return pl;
+  p.m_hx = (unsigned)((1ull << 32) / (unsigned)p.hx) + 1u;
+  p.m_hxy = (unsigned)((1ull << 32) / (unsigned)(p.hx * p.hy)) + 1u;
   p.cblocks = (p.C + 32 * pl.tc - 1) / (32 * pl.tc);
   const int pairs = ((p.N + 32 * pl.tn - 1) / (32 * pl.tn)) * p.cblocks;
   // aim for ~1024 blocks in total
