@@ -184,3 +184,43 @@ def test_c2_shape_64cubed_batch4_properties():
     losses2, _ = forward_loss(gm, cu.build_reference_criterion(), gb2)
     # BatchNorm couples samples only through order-independent batch statistics
     assert rel(losses2[1], losses[1][perm]) < 1e-4
+
+
+def test_rccl_reducer_path_single_rank():
+    """The RCCL code path (bucket hooks, async all-reduce on the process group's stream, join before the
+    optimizer) with a 1-rank group: reductions are identities, so the losses must equal the plain step's."""
+    import torch.distributed as dist
+    import coma_unet_amd as cu
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, make_optimizer
+    from coma_unet_amd.data_parallel import GradReducer, broadcast_module
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        S = (32, 32, 32)
+        b = _gpu_batch(make_batch(2, S, seed=23))
+        losses = []
+        for use_reducer in (False, True):
+            torch.manual_seed(3)
+            gm = cu.build_model(volume_shape=S, static_prompts=True).cuda()
+            gm.set_save_attn(None)
+            gm.train(True)
+            opt = make_optimizer(gm, 1e-3)
+            red = None
+            if use_reducer:
+                broadcast_module(gm)
+                red = GradReducer(opt, bucket_bytes=8 << 20)
+                red.world = 2          # force the multi-rank code path on the 1-rank group
+            crit = cu.build_reference_criterion()
+            ls = [float(train_step(gm, crit, opt, b, red)[0][0]) for _ in range(4)]
+            if use_reducer:
+                assert red._buckets is not None and len(red._buckets) > 4 and len(red._hooks) > 100
+            losses.append(ls)
+        torch.cuda.synchronize()
+        print("plain", losses[0], "reduced", losses[1])
+        for a, r in zip(losses[1], losses[0]):
+            assert abs(a - r) <= 1e-3 * abs(r)    # fp32 atomics in the weight-gradient merge are order-dependent
+    finally:
+        dist.destroy_process_group()
