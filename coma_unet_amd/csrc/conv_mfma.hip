@@ -389,6 +389,214 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
   }
 }
 
+// =====================================================================================
+// conv_mfma_halo2_k -- the production stride-1 3x3x3 kernel for W >= 32, C % 32 == 0.
+// Same tiling as conv_mfma_halo_k (2 x 4 x 32 output voxels x 32 output channels per tile) but
+//  * PERSISTENT: a block walks a contiguous run of tiles of one (sample, 32-channel slice), so the
+//    per-thread staging descriptors are computed once and, when C == 32, ALL 27 taps' weights stay
+//    resident in LDS for the whole kernel (no weight traffic, two barriers per tile);
+//  * LDS images use an 80-byte row pitch instead of an XOR swizzle: 16 rows x 80 B land on 16
+//    distinct 16-B slots of the 256-B bank row, so ds_read_b128 fragment reads stay conflict-free
+//    while every tap/K-step address is `lane base + compile-time immediate` (no VALU per read);
+//  * the MFMA is issued as (weights x voxels): a lane then holds 4 x 4 consecutive output
+//    channels of ONE voxel, and the epilogue is four 8-byte stores per M-tile at immediate offsets;
+//  * the next tile's halo (13 x 16 B per thread) is in flight in registers while this tile computes.
+// PMC on the first halo kernel showed 16 VALU + 4 SALU instructions per MFMA and 54 % of wave
+// cycles waiting; this structure brings the instruction mix under 2 VALU per MFMA.
+// =====================================================================================
+struct Halo2P {
+  const bf16_t* x; int ldx; long sbx; int D, H, W, C;
+  bf16_t* y; int ldy; long sby; int N;
+  const bf16_t* w; long wsb;
+  const float* bias; int bsb;
+  int flip;
+  int ntx, nty, ntz, ids_total, ids_per_block;
+};
+
+template <int RESIDENT>
+__global__ __launch_bounds__(256, 1) void conv_mfma_halo2_k(Halo2P p) {
+  constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
+  constexpr int P = 80;                               // LDS row pitch (bytes) for 32 bf16 channels
+  constexpr int HP = HV * 4, HIT = (HP + 255) / 256;  // halo pieces, per-thread iterations
+  constexpr int WT = RESIDENT ? 27 : 9;               // taps held in LDS at once
+  constexpr int WP = WT * 32 * 4, WIT = (WP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Hl = smem;                                    // [HV][80]
+  char* Wl = smem + HV * P;                           // [WT*32][80]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.z, n0 = blockIdx.y * 32;
+  const int fr = lane & 31, fh = lane >> 5;
+  const bf16_t* xb = p.x + (long)b * p.sbx;
+  const bf16_t* wb = p.w + (long)b * p.wsb;
+  bf16_t* yb = p.y + (long)b * p.sby;
+  const int nchunks = p.C >> 5;
+
+  // ---- staging descriptors (tile independent) ----
+  int h_roff[HIT], h_lds[HIT], h_z[HIT], h_y[HIT], h_x[HIT];
+#pragma unroll
+  for (int it = 0; it < HIT; ++it) {
+    const int piece = tid + 256 * it;
+    const int row = piece >> 2, ch = piece & 3;
+    const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+    h_z[it] = piece < HP ? hz : (1 << 20); h_y[it] = hy; h_x[it] = hx;
+    h_roff[it] = ((hz * p.H + hy) * p.W + hx) * p.ldx + ch * 8;
+    h_lds[it] = row * P + ch * 16;
+  }
+  int w_goff[WIT], w_lds[WIT];
+#pragma unroll
+  for (int it = 0; it < WIT; ++it) {
+    const int piece = tid + 256 * it;
+    const int ch = piece & 3, n = (piece >> 2) & 31, t = piece >> 7;     // t: tap within the LDS image
+    w_goff[it] = (piece < WP && n0 + n < p.N) ? (n0 + n) * p.C + ch * 8 : -1;   // + wtap*N*C + c0 at load time
+    w_lds[it] = (t * 32 + n) * P + ch * 16;
+  }
+  // fragment read bases
+  int a_base[2];   // voxel operand (MFMA B): this lane's voxel row in each of the wave's two M-tiles
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = wid * 2 + i;
+    a_base[i] = (((j >> 2) * HY + (j & 3)) * HX + fr) * P + fh * 16;
+  }
+  const int w_base = fr * P + fh * 16;
+
+  uint4 hreg[HIT], wreg[WIT];
+  auto load_halo = [&](int z0, int y0, int x0, int c0) {
+    const int zb = z0 - 1, yb0 = y0 - 1, xb0 = x0 - 1;
+    const long org = ((long)(zb * p.H + yb0) * p.W + xb0) * p.ldx + c0;
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      const bool ok = (unsigned)(zb + h_z[it]) < (unsigned)p.D && (unsigned)(yb0 + h_y[it]) < (unsigned)p.H &&
+                      (unsigned)(xb0 + h_x[it]) < (unsigned)p.W;
+      hreg[it] = make_uint4(0, 0, 0, 0);
+      if (ok) hreg[it] = *reinterpret_cast<const uint4*>(xb + org + h_roff[it]);
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it)
+      if (tid + 256 * it < HP) *reinterpret_cast<uint4*>(Hl + h_lds[it]) = hreg[it];
+  };
+  auto load_w = [&](int c0, int g) {     // RESIDENT: all 27 taps (g ignored); else kz-plane g
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int piece = tid + 256 * it;
+      const int t = (piece >> 7) + (RESIDENT ? 0 : g * 9);
+      const int wt = p.flip ? 26 - t : t;
+      wreg[it] = make_uint4(0, 0, 0, 0);
+      if (w_goff[it] >= 0) wreg[it] = *reinterpret_cast<const uint4*>(wb + (long)wt * p.N * p.C + c0 + w_goff[it]);
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int it = 0; it < WIT; ++it)
+      if (tid + 256 * it < WP) *reinterpret_cast<uint4*>(Wl + w_lds[it]) = wreg[it];
+  };
+
+  const int id_begin = xcd_remap(blockIdx.x, gridDim.x) * p.ids_per_block;
+  int id_end = id_begin + p.ids_per_block;
+  if (id_end > p.ids_total) id_end = p.ids_total;
+
+  // first valid tile
+  int id = id_begin, tix = 0, tiy = 0, tiz = 0;
+  while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
+  if (id >= id_end) return;
+  if (RESIDENT) { load_w(0, 0); store_w(); }
+  load_halo(tiz * TZ, tiy * TY, tix * TX, 0);
+  if (!RESIDENT) load_w(0, 0);
+
+  float bv[4][4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + 8 * g4 + 4 * fh + q;
+      bv[g4][q] = (p.bias && n < p.N) ? p.bias[b * p.bsb + n] : 0.f;
+    }
+
+  while (id < id_end) {
+    const int x0 = tix * TX, y0 = tiy * TY, z0 = tiz * TZ;
+    // next valid tile (for the prefetch)
+    int nid = id + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nid < id_end && !tile_coords(nid, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nid;
+    const bool has_next = nid < id_end;
+
+    f32x16_t acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    for (int cc = 0; cc < nchunks; ++cc) {
+      __syncthreads();                       // all waves finished reading the previous halo / weights
+      store_halo();
+      if (RESIDENT) {
+        __syncthreads();
+        if (has_next) load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0);
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+          const int toff = (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * P;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const uint4 wv = *reinterpret_cast<const uint4*>(Wl + w_base + t * 32 * P + ks * 32);
+            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&wv);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const uint4 xv = *reinterpret_cast<const uint4*>(Hl + a_base[i] + toff + ks * 32);
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, *reinterpret_cast<const bf16x8_t*>(&xv), acc[i], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int g = 0; g < 3; ++g) {
+          if (g > 0) __syncthreads();        // previous kz-plane's weights are no longer read
+          store_w();
+          __syncthreads();
+          if (g < 2) load_w(cc * 32, g + 1);
+          else if (cc + 1 < nchunks) { load_w(cc * 32 + 32, 0); load_halo(z0, y0, x0, cc * 32 + 32); }
+          else if (has_next) { load_w(0, 0); load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0); }
+          const int gofs = g * HY * HX * P;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * HX + t % 3) * P;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const uint4 wv = *reinterpret_cast<const uint4*>(Wl + w_base + t * 32 * P + ks * 32);
+              const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&wv);
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const uint4 xv = *reinterpret_cast<const uint4*>(Hl + a_base[i] + gofs + toff + ks * 32);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, *reinterpret_cast<const bf16x8_t*>(&xv), acc[i], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+    // ---- epilogue: lane = one voxel, 4 groups of 4 consecutive channels ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = wid * 2 + i;
+      const int gz = z0 + (j >> 2), gy = y0 + (j & 3), gx = x0 + fr;
+      if (gz < p.D && gy < p.H && gx < p.W) {
+        bf16_t* dst = yb + ((long)(gz * p.H + gy) * p.W + gx) * p.ldy + n0 + 4 * fh;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          bf16_t o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = static_cast<bf16_t>(acc[i][g4 * 4 + q] + bv[g4][q]);
+          if (n0 + 8 * g4 + 4 * fh + 3 < p.N) *reinterpret_cast<uint2*>(dst + 8 * g4) = *reinterpret_cast<uint2*>(o);
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (n0 + 8 * g4 + 4 * fh + q < p.N) dst[8 * g4 + q] = o[q];
+          }
+        }
+      }
+    }
+    id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
+  }
+}
+
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 static bool halo_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
@@ -454,6 +662,34 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     return launch_halo<16, 3, 0>(p, x->B, s);
   }
   const bool vec = p.vecx && p.vecw && x->C % 32 == 0;
+  if (vec && lx == 5 && y->ld % 4 == 0 && (((uintptr_t)y->data) & 7) == 0) {
+    Halo2P q;
+    q.x = p.x; q.ldx = p.ldx; q.sbx = p.sbx; q.D = p.D; q.H = p.H; q.W = p.W; q.C = p.C;
+    q.y = p.y; q.ldy = p.ldy; q.sby = p.sby; q.N = p.N; q.w = p.w; q.wsb = p.wsb; q.bias = p.bias; q.bsb = p.bsb;
+    q.flip = p.flip;
+    q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
+    q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
+    const int nblk_n = (q.N + 31) / 32;
+    int gx = 512 / (nblk_n * x->B);           // ~2 rounds of 256 one-per-CU blocks
+    if (gx < 1) gx = 1;
+    if (gx > q.ids_total) gx = q.ids_total;
+    q.ids_per_block = (q.ids_total + gx - 1) / gx;
+    gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
+    dim3 grid((unsigned)gx, (unsigned)nblk_n, (unsigned)x->B);
+    constexpr int HV2 = 34 * 6 * 4;
+    const bool resident = q.C == 32;
+    const size_t lds = (size_t)HV2 * 80 + (size_t)(resident ? 27 : 9) * 32 * 80;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    if (resident) hipLaunchKernelGGL((conv_mfma_halo2_k<1>), grid, dim3(256), lds, s, q);
+    else hipLaunchKernelGGL((conv_mfma_halo2_k<0>), grid, dim3(256), lds, s, q);
+    COMA_LAUNCH_CHECK();
+    return 0;
+  }
   if (vec) {
     if (lx == 5) return launch_halo<32, 5, 1>(p, x->B, s);
     if (lx == 4) return launch_halo<32, 4, 1>(p, x->B, s);

@@ -331,6 +331,9 @@ MFMA_CASES = [
     (32, 32, 3, 1, False, (6, 9, 37)), (64, 32, 3, 1, False, (5, 8, 33)), (32, 64, 3, 2, False, (8, 10, 36)),
     (64, 32, 3, 2, True, (4, 5, 17)), (128, 128, 3, 1, False, (4, 4, 8)), (256, 128, 3, 2, True, (2, 3, 4)),
     (32, 64, 1, 1, False, (5, 6, 7)), (64, 64, 3, 1, False, (3, 3, 3)), (32, 32, 3, 2, False, (7, 9, 11)),
+    # persistent halo kernel (W >= 32): resident weights (C == 32) and streamed kz-planes (C > 32), ragged grids
+    (32, 32, 3, 1, False, (20, 21, 70)), (32, 64, 3, 1, False, (17, 10, 33)), (64, 32, 3, 1, False, (18, 9, 64)),
+    (96, 64, 3, 1, False, (3, 5, 40)), (32, 96, 3, 1, False, (35, 4, 32)),
 ]
 
 
