@@ -52,10 +52,19 @@ class RoiMSE(nn.Module):
     def update_weights(self, weights):   # criterions.py:170-172 (a no-op upstream)
         return
 
+    def _tables(self, dev):
+        """ROI id / weight tables on the device, rebuilt only when the weights object changes
+        (no host->device copy inside the step: keeps it hipGraph-capturable)."""
+        key = (dev, id(self.roi_weights), getattr(self.roi_weights, "_version", 0), tuple(self.roi_indices))
+        if getattr(self, "_tab_key", None) != key:
+            self._tab = (torch.as_tensor(list(self.roi_indices), dtype=torch.int32, device=dev),
+                         torch.as_tensor(self.roi_weights, dtype=torch.float32).to(dev).contiguous())
+            self._tab_key = key
+        return self._tab
+
     def forward(self, pred, gt, roi):
         dev = pred.device
-        ids = torch.as_tensor(list(self.roi_indices), dtype=torch.int32, device=dev)
-        w = torch.as_tensor(self.roi_weights, dtype=torch.float32).to(dev).contiguous()
+        ids, w = self._tables(dev)
         p = _vol_internal(pred)
         loss = ops.RoiMSELoss.apply(p, _vol_internal(gt, p.dtype).contiguous(),
                                     _vol_internal(roi, torch.float32).contiguous(), ids, w)   # (B, 1)
@@ -121,10 +130,16 @@ class RnCLoss(nn.Module):
         logits = logits - logits_max.detach()
         exp_logits = logits.exp()
         n = logits.shape[0]
-        off = ~torch.eye(n, dtype=torch.bool, device=logits.device)
-        logits = logits.masked_select(off).view(n, n - 1)
-        exp_logits = exp_logits.masked_select(off).view(n, n - 1)
-        label_diffs = label_diffs.masked_select(off).view(n, n - 1)
+        # remove the diagonal with a static gather (masked_select would need a host sync)
+        key = (n, logits.device)
+        if getattr(self, "_offdiag_key", None) != key:
+            cols = [[j for j in range(n) if j != i] for i in range(n)]
+            self._offdiag = torch.tensor(cols, dtype=torch.long).reshape(n, max(n - 1, 0)).to(logits.device)
+            self._offdiag_key = key
+        idx = self._offdiag
+        logits = torch.gather(logits, 1, idx)
+        exp_logits = torch.gather(exp_logits, 1, idx)
+        label_diffs = torch.gather(label_diffs, 1, idx)
         loss = 0.0
         for k in range(n - 1):
             pos_logits = logits[:, k]

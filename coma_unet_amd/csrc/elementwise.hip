@@ -401,7 +401,13 @@ extern "C" int coma_l1_bwd(const coma_tensor* pred, const coma_tensor* gt, const
 
 // ---- AdamW (torch.optim.AdamW: decoupled decay, bias-corrected, eps outside sqrt(v_hat)) ----
 __global__ __launch_bounds__(256) void adamw_k(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
-                                               float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                                               float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                               const int32_t* step_dev) {
+  if (step_dev) {   // step count lives on the device (hipGraph replays must not freeze it)
+    const float st = (float)*step_dev;
+    bc1 = 1.f - powf(b1, st);
+    bc2_sqrt = sqrtf(1.f - powf(b2, st));
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i];
     float pi = p[i] * (1.f - lr * wd);
@@ -414,13 +420,13 @@ __global__ __launch_bounds__(256) void adamw_k(float* p, const float* g, float* 
   }
 }
 extern "C" int coma_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                          float eps, float weight_decay, int32_t step, void* stream) {
-  COMA_CHECK(p && g && m && v && n >= 0 && step >= 1, "adamw: bad argument");
+                          float eps, float weight_decay, int32_t step, const int32_t* step_dev, void* stream) {
+  COMA_CHECK(p && g && m && v && n >= 0 && (step >= 1 || step_dev), "adamw: bad argument");
   if (n == 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, sqrtf(bc2));
+                     weight_decay, bc1, sqrtf(bc2), step_dev);
   COMA_LAUNCH_CHECK();
   return 0;
 }

@@ -418,8 +418,8 @@ class L1Loss(Function):
         return dpred, None
 
 
-def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step):
-    """In-place fused AdamW on flat fp32 buffers."""
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, step_dev=None):
+    """In-place fused AdamW on flat fp32 buffers (step_dev: device int32 step counter, for graph replay)."""
     assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32
-    check(lib.coma_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step, L.stream()),
-          "coma_adamw")
+    check(lib.coma_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step, ptr(step_dev),
+                         L.stream()), "coma_adamw")

@@ -47,6 +47,7 @@ class FusedAdamW(torch.optim.Optimizer):
             off += k
         self._flat_params = ps
         self._flat_ids = {id(p) for p in ps}
+        self._step_dev = torch.full((1,), self._flat_step, dtype=torch.int32, device=dev)
 
     @property
     def built(self):
@@ -68,7 +69,9 @@ class FusedAdamW(torch.optim.Optimizer):
         if not self.built:
             self._build()
         self._flat_step += 1
-        ops.adamw_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, lr, b1, b2, eps, wd, self._flat_step)
+        self._step_dev += 1            # device-side copy: a captured step keeps counting under graph replay
+        ops.adamw_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, lr, b1, b2, eps, wd, self._flat_step,
+                   self._step_dev)
         for p in g["params"]:
             if id(p) in self._flat_ids or p.grad is None:
                 continue
@@ -114,6 +117,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 self.flat_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
                 self.flat_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
                 self._flat_step = int(st["step"])
+                self._step_dev.fill_(self._flat_step)
             else:
                 self.state[p] = {"step": int(st["step"]), "exp_avg": st["exp_avg"].to(p.device).float().clone(),
                                  "exp_avg_sq": st["exp_avg_sq"].to(p.device).float().clone()}

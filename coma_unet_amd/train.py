@@ -40,3 +40,41 @@ def train_step(model, criterion, optimizer, batch, reducer: GradReducer = None):
         reducer.finish()
     optimizer.step()                                                        # :885
     return losses, outs
+
+
+class GraphedTrainStep:
+    """The whole step (zero_grad + forward + loss + backward + fused AdamW) captured in ONE hipGraph and
+    replayed: ~450 kernel launches per step collapse into one graph launch, which removes the host launch
+    gaps (the reference's step is launch-bound in the same way on its cuDNN path).  Requirements: a model
+    built with ``static_prompts=True`` (no host read of the covariates), ROI priors passed as a (B,36,2)
+    tensor, fixed shapes.  New data is copied into the static input buffers before each replay.
+    Single-GPU only: the data-parallel path keeps the eager step with hook-driven bucket all-reduce.
+    """
+
+    def __init__(self, model, criterion, optimizer, batch, warmup=3):
+        assert getattr(model, "static_prompts", False), "graph capture needs static_prompts=True"
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        assert torch.is_tensor(self.batch["roi_pred_dicts"]), "pass ROI priors as a (B, 36, 2) device tensor"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 2)):      # builds the flat optimizer layout, sizes workspaces
+                train_step(model, criterion, optimizer, self.batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.losses, self.outputs = train_step(model, criterion, optimizer, self.batch)
+
+    def load(self, batch):
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                self.batch[k].copy_(v, non_blocking=True)
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            self.load(batch)
+        self.graph.replay()
+        self.optimizer._flat_step += 1
+        return self.losses, self.outputs

@@ -164,9 +164,11 @@ int coma_l1_bwd(const coma_tensor* pred, const coma_tensor* gt, const float* gou
                 const coma_tensor* dpred, void* stream);
 
 /* ---- AdamW over a flat fp32 buffer (torch.optim.AdamW defaults,
- *      attn_unet_data_parallel.py:736): p,g,m,v length n; step counted from 1 ---- */
+ *      attn_unet_data_parallel.py:736): p,g,m,v length n; step counted from 1.  When step_dev is
+ *      non-NULL the step count is read from that device int32 instead (hipGraph replay). ---- */
 int coma_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-               float beta2, float eps, float weight_decay, int32_t step, void* stream);
+               float beta2, float eps, float weight_decay, int32_t step, const int32_t* step_dev,
+               void* stream);
 
 #ifdef __cplusplus
 }

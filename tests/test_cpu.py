@@ -130,3 +130,17 @@ def test_hot_path_refuses_cpu_tensors():
     b = make_batch(1, (16, 16, 16), seed=0)
     with pytest.raises((AssertionError, RuntimeError)):
         m(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])
+
+
+def test_product_rnc_matches_reference_golden():
+    """coma_unet_amd.criterions.RnCLoss (capture-safe gather instead of masked_select) vs the reference's values."""
+    from coma_unet_amd import criterions as prod
+    g = np.load(os.path.join(GOLD, "criterions_ref.npz"))
+    for ci in range(6):
+        feats = torch.from_numpy(g[f"rnc{ci}_features"]).requires_grad_(True)
+        labels = torch.from_numpy(g[f"rnc{ci}_labels"])
+        loss = prod.RnCLoss()(feats, labels)
+        assert abs(float(loss) - float(g[f"rnc{ci}_loss"])) <= 1e-6 * max(1.0, abs(float(g[f"rnc{ci}_loss"])))
+        if torch.is_tensor(loss) and loss.requires_grad:
+            loss.backward()
+            assert rel(feats.grad, g[f"rnc{ci}_grad"]) < 1e-5

@@ -224,3 +224,31 @@ def test_rccl_reducer_path_single_rank():
             assert abs(a - r) <= 1e-3 * abs(r)    # fp32 atomics in the weight-gradient merge are order-dependent
     finally:
         dist.destroy_process_group()
+
+
+def test_graphed_step_matches_eager_steps():
+    """The hipGraph-captured step (bench.py's one-GPU launch mode) must walk the same loss trajectory."""
+    import coma_unet_amd as cu
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, make_optimizer, GraphedTrainStep
+    S = (32, 32, 32)
+    b = make_batch(2, S, seed=29)
+    traj = []
+    for graphed in (False, True):
+        torch.manual_seed(4)
+        gm = cu.build_model(volume_shape=S, static_prompts=True, compute_dtype=torch.bfloat16).cuda()
+        gm.set_save_attn(None)
+        gm.train(True)
+        gb = _gpu_batch(b)
+        gb["roi_pred_dicts"] = gm._priors(b["roi_pred_dicts"], 2, torch.device("cuda"))
+        opt = make_optimizer(gm, 1e-3)
+        crit = cu.build_reference_criterion()
+        if graphed:
+            step = GraphedTrainStep(gm, crit, opt, gb, warmup=2)       # 2 eager warm-up steps inside
+            ls = [float(step()[0][0]) for _ in range(3)]
+        else:
+            ls = [float(train_step(gm, crit, opt, gb)[0][0]) for _ in range(5)][2:]
+        traj.append(ls)
+    print("eager", traj[0], "graph", traj[1])
+    for a, r in zip(traj[1], traj[0]):
+        assert abs(a - r) <= 2e-2 * abs(r)     # bf16 + atomics: run-to-run noise, amplified by Adam
