@@ -909,6 +909,210 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
   }
 }
 
+// =====================================================================================
+// conv_mfma_wgrad2_k -- stride-1 3x3x3 weight gradient for W >= 32 (any channel counts; one
+// 32(n) x 32(c) slab of dwk per block, thin layers are zero-padded in LDS once).
+// Same algorithm as conv_mfma_wgrad_k, restructured after its PMC profile (14.6 VALU + 7 SALU per
+// MFMA, 64 % of wave cycles waiting): the tile is fixed at 2 x 4 x 32 voxels so that EVERY
+// transposed LDS read is `lane base + compile-time immediate` (16 fully unrolled K steps x the
+// wave's 7 taps, code specialised per wave), the per-thread staging descriptors are hoisted out
+// of the tile loop, invalid (padding-channel) pieces are never staged, and all of a tile's global
+// loads are issued before the first is consumed.
+// =====================================================================================
+struct Wgrad2P {
+  const bf16_t* dyp; int ldn; long sbn;
+  const bf16_t* xp; int ldc; long sbc;
+  int N, C, D, H, W;
+  int ntx, nty, ntz, tiles_total, tiles_per_block, cblocks;
+  int vec_n, vec_c;
+  float* dwk; long wsb;
+};
+
+// One tile's MFMAs for the calling wave.  toff[t] = LDS byte offset of the wave's t-th tap (wave-uniform
+// scalars, so each gathered read costs one v_add with an SGPR operand; K-step offsets are scalars too and
+// the +4-voxel second read is an immediate).
+__device__ __forceinline__ void wgrad2_tile(const char* Dt, const char* Gt, int lane_d, int lane_g, const int (&toff)[7],
+                                            int ntap, f32x16_t (&acc)[7]) {
+  constexpr int HX = 34, HY = 6, PD = 64, PG = 64;
+#pragma unroll 2
+  for (int ks = 0; ks < 16; ++ks) {
+    // K step ks = 16 consecutive x of row (z = ks >> 3, y = (ks >> 1) & 3), x half = ks & 1
+    const int z = ks >> 3, y = (ks >> 1) & 3, xh = ks & 1;
+    const char* dp = Dt + lane_d + ((z * 4 + y) * 32 + xh * 16) * PD;
+    const char* gp = Gt + lane_g + ((z * HY + y) * HX + xh * 16) * PG;
+    const s4_t dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(dp));
+    const s4_t dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(dp + 4 * PD));
+    const bf16x8_t df = (bf16x8_t){dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      if (t < ntap) {
+        const s4_t glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(gp + toff[t]));
+        const s4_t ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(gp + toff[t] + 4 * PG));
+        const bf16x8_t gf = (bf16x8_t){glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, gf, acc[t], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int VEC, int OCC>   // VEC=1: every staged piece is a legal, fully valid 16-byte load; OCC = blocks per CU
+__global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
+  constexpr int TX = 32, TY = 4, TZ = 2, TM = TX * TY * TZ, HX = 34, HY = 6, HZ = 4, HV = HX * HY * HZ;
+  constexpr int NDP = TM * 4, NGP = HV * 4;                     // 16-byte pieces (dense, halo)
+  constexpr int DIT = NDP / 256, GIT = (NGP + 255) / 256;        // 4 and 13 per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Dt = smem;                 // dense dy tile  [TM][32 ch]
+  char* Gt = smem + TM * 64;       // gathered x halo [HV][32 ch]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the per-wave code paths below are scalar branches
+  const int b = blockIdx.z;
+  const int nb = blockIdx.y / p.cblocks, cb = blockIdx.y % p.cblocks;
+  const int n0 = nb * 32, c0 = cb * 32;
+  const bf16_t* dyb = p.dyp + (long)b * p.sbn + n0;
+  const bf16_t* xb = p.xp + (long)b * p.sbc + c0;
+  const int chn = p.N - n0, chc = p.C - c0;      // valid channels of this block's slices
+  const int ch = tid & 3;                        // every piece of this thread has the same 8-channel chunk
+  const bool dlive = ch * 8 < chn, glive = ch * 8 < chc;
+
+  // zero the whole LDS image once: padding channels / never-staged pieces stay zero
+  for (int i = tid; i < NDP + NGP; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+  f32x16_t acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  const int g16 = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int vrow = 8 * (g16 >> 1) + q;                          // voxel within a 16-voxel K step
+  const int chan_b = ((g16 & 1) * 16 + 4 * pp) * 2;
+  const int lane_d = vrow * 64 + chan_b;
+  const int lane_g = vrow * 64 + chan_b;
+
+  int toff[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = wid + 4 * t;
+    toff[t] = __builtin_amdgcn_readfirstlane((((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64);
+  }
+  const int ntap = wid == 3 ? 6 : 7;
+
+  const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * p.tiles_per_block;
+  int tile_end = tile_begin + p.tiles_per_block;
+  if (tile_end > p.tiles_total) tile_end = p.tiles_total;
+
+  // ---- software pipeline: tile t+1's global loads are in flight (registers) while tile t computes ----
+  uint4 dv[DIT], gv[GIT];
+  auto load_tile = [&](int x0, int y0, int z0) {
+    if (dlive) {
+#pragma unroll
+      for (int it = 0; it < DIT; ++it) {
+        const int row = (tid >> 2) + 64 * it;
+        const int vx = row & 31, vy = (row >> 5) & 3, vz = row >> 7;
+        const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+        dv[it] = make_uint4(0, 0, 0, 0);
+        if (gz < p.D && gy < p.H && gx < p.W) {
+          const bf16_t* src = dyb + (unsigned)(((gz * p.H + gy) * p.W + gx) * p.ldn + ch * 8);   // < 2^31 elements (checked)
+          dv[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8(src, chn - ch * 8, p.vec_n);
+        }
+      }
+    }
+    if (glive) {
+#pragma unroll
+      for (int it = 0; it < GIT; ++it) {
+        const int row = (tid >> 2) + 64 * it;
+        const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        gv[it] = make_uint4(0, 0, 0, 0);
+        if (row < HV && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
+          const bf16_t* src = xb + (unsigned)(((gz * p.H + gy) * p.W + gx) * p.ldc + ch * 8);
+          gv[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8(src, chc - ch * 8, p.vec_c);
+        }
+      }
+    }
+  };
+  auto store_tile = [&]() {
+    if (dlive) {
+#pragma unroll
+      for (int it = 0; it < DIT; ++it) reinterpret_cast<uint4*>(Dt)[tid + 256 * it] = dv[it];
+    }
+    if (glive) {
+#pragma unroll
+      for (int it = 0; it < GIT; ++it)
+        if (tid + 256 * it < NGP) reinterpret_cast<uint4*>(Gt)[tid + 256 * it] = gv[it];
+    }
+  };
+
+  int tile = tile_begin, tix = 0, tiy = 0, tiz = 0;
+  while (tile < tile_end && !tile_coords(tile, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++tile;
+  if (tile < tile_end) load_tile(tix * TX, tiy * TY, tiz * TZ);
+  while (tile < tile_end) {
+    int nt = tile + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nt < tile_end && !tile_coords(nt, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nt;
+    __syncthreads();     // previous tile's LDS reads are done
+    store_tile();
+    __syncthreads();
+    if (OCC == 1) { if (nt < tile_end) load_tile(ntix * TX, ntiy * TY, ntiz * TZ); }   // prefetch under the MFMAs
+    wgrad2_tile(Dt, Gt, lane_d, lane_g, toff, ntap, acc);
+    if (OCC != 1) { if (nt < tile_end) load_tile(ntix * TX, ntiy * TY, ntiz * TZ); }   // the co-resident block covers this latency
+    tile = nt;
+  }
+  // ---- merge into dwk[b][tap][n][c] ----
+  float* wout = p.dwk + (long)b * p.wsb;
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = wid + 4 * t;
+    if (tap < 27) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int c = c0 + fr;
+        if (n < p.N && c < p.C) atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, acc[t][e]);
+      }
+    }
+  }
+}
+
+static bool wgrad2_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  return d->form == 0 && d->stride == 1 && d->ksize == 3 && x->dtype == COMA_BF16 && dy->dtype == COMA_BF16 &&
+         x->W >= 32 && (long)t_vox(x) * x->ld < (1L << 31) && (long)t_vox(dy) * dy->ld < (1L << 31);
+}
+
+static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s) {
+  Wgrad2P p;
+  p.dyp = (const bf16_t*)dy->data; p.ldn = (int)dy->ld; p.sbn = dy->sb;
+  p.xp = (const bf16_t*)x->data; p.ldc = (int)x->ld; p.sbc = x->sb;
+  p.N = dy->C; p.C = x->C; p.D = x->D; p.H = x->H; p.W = x->W;
+  p.ntx = (p.W + 31) / 32; p.nty = (p.H + 3) / 4; p.ntz = (p.D + 1) / 2;
+  p.tiles_total = p.ntx * p.nty * ((p.ntz + 7) / 8) * 8;
+  p.cblocks = (p.C + 31) / 32;
+  const int pairs = ((p.N + 31) / 32) * p.cblocks;
+  p.vec_n = dy->ld % 8 == 0 && dy->sb % 8 == 0 && (((uintptr_t)dy->data) & 15) == 0;
+  p.vec_c = x->ld % 8 == 0 && x->sb % 8 == 0 && (((uintptr_t)x->data) & 15) == 0;
+  int chunks = 1024 / (pairs * x->B);
+  if (chunks < 1) chunks = 1;
+  if (chunks > p.tiles_total) chunks = p.tiles_total;
+  p.tiles_per_block = (p.tiles_total + chunks - 1) / chunks;
+  chunks = (p.tiles_total + p.tiles_per_block - 1) / p.tiles_per_block;
+  p.dwk = dwk; p.wsb = d->per_sample_w ? 27L * p.N * p.C : 0;
+  const long wsz = 27L * p.N * p.C * (d->per_sample_w ? x->B : 1);
+  if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  const size_t lds = (size_t)(256 + 816) * 64;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr = true;
+  }
+  const bool vec = p.vec_n && p.vec_c && p.N % 8 == 0 && p.C % 8 == 0;
+  const dim3 grid((unsigned)chunks, (unsigned)pairs, (unsigned)x->B);
+  if (vec) hipLaunchKernelGGL((conv_mfma_wgrad2_k<1, 2>), grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL((conv_mfma_wgrad2_k<0, 1>), grid, dim3(256), lds, s, p);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
 static int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 struct WgradPlan { WgradP2 p; int TM; size_t lds; int tn, tc; dim3 grid; bool ok; };
@@ -969,12 +1173,13 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
 }
 
 bool conv_mfma_wgrad_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
-  return wgrad_plan(d, x, dy).ok;
+  return wgrad2_ok(d, x, dy) || wgrad_plan(d, x, dy).ok;
 }
 size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc*, const coma_tensor*, const coma_tensor*) { return 0; }
 
 int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void*, size_t,
                     hipStream_t s) {
+  if (wgrad2_ok(d, x, dy)) return conv_mfma_wgrad2(d, x, dy, dwk, s);
   WgradPlan pl = wgrad_plan(d, x, dy);
   COMA_CHECK(pl.ok, "conv_mfma_wgrad: unsupported problem");
   pl.p.dwk = dwk;
