@@ -409,17 +409,20 @@ struct Halo2P {
   bf16_t* y; int ldy; long sby; int N;
   const bf16_t* w; long wsb;
   const float* bias; int bsb;
-  int flip;
+  int flip, vecx, vecw;
   int ntx, nty, ntz, ids_total, ids_per_block;
 };
 
-template <int RESIDENT>
-__global__ __launch_bounds__(256, 1) void conv_mfma_halo2_k(Halo2P p) {
+// CK = channels per LDS row (32, or 16 for the thin full-resolution layers: one MFMA K step per tap);
+// VEC = every 8-channel piece is a legal, fully valid 16-byte load; OCC = blocks per CU.
+template <int RESIDENT, int CK, int VEC, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
-  constexpr int P = 80;                               // LDS row pitch (bytes) for 32 bf16 channels
-  constexpr int HP = HV * 4, HIT = (HP + 255) / 256;  // halo pieces, per-thread iterations
+  constexpr int CPR = CK / 8, KS = CK / 16;          // 16-byte pieces per row, MFMA K steps per tap
+  constexpr int P = CK == 32 ? 80 : 48;               // LDS row pitch (bytes): 16 rows land on 16 distinct 16-B slots
+  constexpr int HP = HV * CPR, HIT = (HP + 255) / 256;  // halo pieces, per-thread iterations
   constexpr int WT = RESIDENT ? 27 : 9;               // taps held in LDS at once
-  constexpr int WP = WT * 32 * 4, WIT = (WP + 255) / 256;
+  constexpr int WP = WT * 32 * CPR, WIT = (WP + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Hl = smem;                                    // [HV][80]
   char* Wl = smem + HV * P;                           // [WT*32][80]
@@ -429,24 +432,26 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_halo2_k(Halo2P p) {
   const bf16_t* xb = p.x + (long)b * p.sbx;
   const bf16_t* wb = p.w + (long)b * p.wsb;
   bf16_t* yb = p.y + (long)b * p.sby;
-  const int nchunks = p.C >> 5;
+  const int nchunks = (p.C + CK - 1) / CK;
 
   // ---- staging descriptors (tile independent) ----
-  int h_roff[HIT], h_lds[HIT], h_z[HIT], h_y[HIT], h_x[HIT];
+  int h_roff[HIT], h_lds[HIT], h_z[HIT], h_y[HIT], h_x[HIT], h_ch[HIT];
 #pragma unroll
   for (int it = 0; it < HIT; ++it) {
     const int piece = tid + 256 * it;
-    const int row = piece >> 2, ch = piece & 3;
+    const int row = piece / CPR, ch = piece % CPR;
     const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
     h_z[it] = piece < HP ? hz : (1 << 20); h_y[it] = hy; h_x[it] = hx;
+    h_ch[it] = ch * 8;
     h_roff[it] = ((hz * p.H + hy) * p.W + hx) * p.ldx + ch * 8;
     h_lds[it] = row * P + ch * 16;
   }
-  int w_goff[WIT], w_lds[WIT];
+  int w_goff[WIT], w_lds[WIT], w_ch[WIT];
 #pragma unroll
   for (int it = 0; it < WIT; ++it) {
     const int piece = tid + 256 * it;
-    const int ch = piece & 3, n = (piece >> 2) & 31, t = piece >> 7;     // t: tap within the LDS image
+    const int ch = piece % CPR, n = (piece / CPR) & 31, t = piece / (CPR * 32);     // t: tap within the LDS image
+    w_ch[it] = ch * 8;
     w_goff[it] = (piece < WP && n0 + n < p.N) ? (n0 + n) * p.C + ch * 8 : -1;   // + wtap*N*C + c0 at load time
     w_lds[it] = (t * 32 + n) * P + ch * 16;
   }
@@ -468,7 +473,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_halo2_k(Halo2P p) {
       const bool ok = (unsigned)(zb + h_z[it]) < (unsigned)p.D && (unsigned)(yb0 + h_y[it]) < (unsigned)p.H &&
                       (unsigned)(xb0 + h_x[it]) < (unsigned)p.W;
       hreg[it] = make_uint4(0, 0, 0, 0);
-      if (ok) hreg[it] = *reinterpret_cast<const uint4*>(xb + org + h_roff[it]);
+      if (VEC) { if (ok) hreg[it] = *reinterpret_cast<const uint4*>(xb + org + h_roff[it]); }
+      else if (ok && c0 + h_ch[it] < p.C) hreg[it] = load8(xb + org + h_roff[it], p.C - c0 - h_ch[it], p.vecx);
     }
   };
   auto store_halo = [&]() {
@@ -480,10 +486,12 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_halo2_k(Halo2P p) {
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
       const int piece = tid + 256 * it;
-      const int t = (piece >> 7) + (RESIDENT ? 0 : g * 9);
+      const int t = piece / (CPR * 32) + (RESIDENT ? 0 : g * 9);
       const int wt = p.flip ? 26 - t : t;
       wreg[it] = make_uint4(0, 0, 0, 0);
-      if (w_goff[it] >= 0) wreg[it] = *reinterpret_cast<const uint4*>(wb + (long)wt * p.N * p.C + c0 + w_goff[it]);
+      if (VEC) { if (w_goff[it] >= 0) wreg[it] = *reinterpret_cast<const uint4*>(wb + (long)wt * p.N * p.C + c0 + w_goff[it]); }
+      else if (w_goff[it] >= 0 && c0 + w_ch[it] < p.C)
+        wreg[it] = load8(wb + (long)wt * p.N * p.C + c0 + w_goff[it], p.C - c0 - w_ch[it], p.vecw);
     }
   };
   auto store_w = [&]() {
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_halo2_k(Halo2P p) {
         for (int t = 0; t < 27; ++t) {
           const int toff = (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * P;
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
+          for (int ks = 0; ks < KS; ++ks) {
             const uint4 wv = *reinterpret_cast<const uint4*>(Wl + w_base + t * 32 * P + ks * 32);
             const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&wv);
 #pragma unroll
@@ -552,15 +560,15 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_halo2_k(Halo2P p) {
           if (g > 0) __syncthreads();        // previous kz-plane's weights are no longer read
           store_w();
           __syncthreads();
-          if (g < 2) load_w(cc * 32, g + 1);
-          else if (cc + 1 < nchunks) { load_w(cc * 32 + 32, 0); load_halo(z0, y0, x0, cc * 32 + 32); }
+          if (g < 2) load_w(cc * CK, g + 1);
+          else if (cc + 1 < nchunks) { load_w(cc * CK + CK, 0); load_halo(z0, y0, x0, cc * CK + CK); }
           else if (has_next) { load_w(0, 0); load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0); }
           const int gofs = g * HY * HX * P;
 #pragma unroll
           for (int t = 0; t < 9; ++t) {
             const int toff = ((t / 3) * HX + t % 3) * P;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
               const uint4 wv = *reinterpret_cast<const uint4*>(Wl + w_base + t * 32 * P + ks * 32);
               const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&wv);
 #pragma unroll
@@ -656,39 +664,41 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
   p.vecw = x->C % 8 == 0 && aligned16(wk);
   const bool thin = x->C <= 16;
   const int lx = x->W >= 32 ? 5 : (x->W >= 16 ? 4 : 3);
-  if (thin) {
-    if (lx == 5) return launch_halo<16, 5, 0>(p, x->B, s);
-    if (lx == 4) return launch_halo<16, 4, 0>(p, x->B, s);
-    return launch_halo<16, 3, 0>(p, x->B, s);
-  }
   const bool vec = p.vecx && p.vecw && x->C % 32 == 0;
-  if (vec && lx == 5 && y->ld % 4 == 0 && (((uintptr_t)y->data) & 7) == 0) {
+  if (lx == 5 && y->ld % 4 == 0 && (((uintptr_t)y->data) & 7) == 0 && (thin || vec)) {
     Halo2P q;
     q.x = p.x; q.ldx = p.ldx; q.sbx = p.sbx; q.D = p.D; q.H = p.H; q.W = p.W; q.C = p.C;
     q.y = p.y; q.ldy = p.ldy; q.sby = p.sby; q.N = p.N; q.w = p.w; q.wsb = p.wsb; q.bias = p.bias; q.bsb = p.bsb;
-    q.flip = p.flip;
+    q.flip = p.flip; q.vecx = p.vecx; q.vecw = p.vecw;
     q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
     q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
     const int nblk_n = (q.N + 31) / 32;
-    int gx = 512 / (nblk_n * x->B);           // ~2 rounds of 256 one-per-CU blocks
+    int gx = (thin ? 1024 : 512) / (nblk_n * x->B);   // thin: 2 blocks per CU, thick: 1
     if (gx < 1) gx = 1;
     if (gx > q.ids_total) gx = q.ids_total;
     q.ids_per_block = (q.ids_total + gx - 1) / gx;
     gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
     dim3 grid((unsigned)gx, (unsigned)nblk_n, (unsigned)x->B);
     constexpr int HV2 = 34 * 6 * 4;
-    const bool resident = q.C == 32;
-    const size_t lds = (size_t)HV2 * 80 + (size_t)(resident ? 27 : 9) * 32 * 80;
+    const bool resident = thin || q.C == 32;
+    const size_t lds = thin ? (size_t)(HV2 + 27 * 32) * 48 : (size_t)HV2 * 80 + (size_t)(resident ? 27 : 9) * 32 * 80;
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<1, 32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<0, 32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<1, 16, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       attr = true;
     }
-    if (resident) hipLaunchKernelGGL((conv_mfma_halo2_k<1>), grid, dim3(256), lds, s, q);
-    else hipLaunchKernelGGL((conv_mfma_halo2_k<0>), grid, dim3(256), lds, s, q);
+    if (thin) hipLaunchKernelGGL((conv_mfma_halo2_k<1, 16, 0, 2>), grid, dim3(256), lds, s, q);
+    else if (resident) hipLaunchKernelGGL((conv_mfma_halo2_k<1, 32, 1, 1>), grid, dim3(256), lds, s, q);
+    else hipLaunchKernelGGL((conv_mfma_halo2_k<0, 32, 1, 1>), grid, dim3(256), lds, s, q);
     COMA_LAUNCH_CHECK();
     return 0;
+  }
+  if (thin) {
+    if (lx == 5) return launch_halo<16, 5, 0>(p, x->B, s);
+    if (lx == 4) return launch_halo<16, 4, 0>(p, x->B, s);
+    return launch_halo<16, 3, 0>(p, x->B, s);
   }
   if (vec) {
     if (lx == 5) return launch_halo<32, 5, 1>(p, x->B, s);
