@@ -27,8 +27,8 @@ FP32_VALU_PEAK_TFLOPS = 157.3
 UNET_TFLOP_PER_VOLUME_128 = 2.340  # BASELINE.md section 2 (U-Net fwd+bwd, 128^3)
 
 
-def cpu_baseline(size, threads):
-    """One fwd+bwd step of the CPU oracle at `size`^3, batch 1 (bounded sample of the same workload)."""
+def cpu_baseline(size, threads, batch=2):
+    """One fwd+bwd step of the CPU oracle at `size`^3 on the same per-GPU batch (bounded sample of the workload)."""
     from oracle.coma_oracle import build_reference_model
     from oracle.criterions_oracle import build_reference_criterion, train_step_loss
     from coma_unet_amd.synthetic import make_batch
@@ -38,15 +38,15 @@ def cpu_baseline(size, threads):
     m = build_reference_model(volume_shape=S, double_forward=False)
     m.set_save_attn(None)
     m.train(True)
-    b = make_batch(1, S, seed=0)
+    b = make_batch(batch, S, seed=0)
     crit = build_reference_criterion()
     t0 = time.perf_counter()
     out = m(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])
     train_step_loss(out, b["tau"], b["roi"], b["covars"], crit)[0].backward()
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "volumes/s", "cores": threads, "kind": "port",
+    return {"value": batch / dt, "unit": "volumes/s", "cores": threads, "kind": "port",
             "sample": f"CPU oracle (torch {torch.__version__}, fp32, single U-Net pass), 1 fwd+bwd step, "
-                      f"batch 1 at {size}^3, {dt:.1f} s"}
+                      f"batch {batch} at {size}^3, {dt:.1f} s"}
 
 
 def main():
@@ -177,7 +177,7 @@ def main():
             except Exception:
                 threads = os.cpu_count() or 1
             threads = min(threads, 16)   # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
-            line["cpu_baseline"] = cpu_baseline(args.size, threads)
+            line["cpu_baseline"] = cpu_baseline(args.size, threads, args.batch)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

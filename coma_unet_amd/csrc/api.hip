@@ -24,7 +24,11 @@ int colsum(const coma_tensor* x, int per_sample, float* out, void* ws, size_t ws
 // conv_mfma.hip
 bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
-                  const coma_tensor* y, hipStream_t s);
+                  const coma_tensor* y, hipStream_t s, double2* stats = nullptr, int stats_inst = 0,
+                  int* stats_chunks = nullptr);
+// norm.hip
+int norm_stats_finalize(const double2* partial, int nchunks, int G, int C, int64_t R, float eps, float* mean, float* rstd,
+                        float* running_mean, float* running_var, float momentum, hipStream_t s);
 bool conv_mfma_wgrad_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
 size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
 int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws,
@@ -54,6 +58,31 @@ extern "C" int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, cons
 extern "C" int coma_conv_wgrad_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   if (d->algo == 1) return 1;
   return (x->dtype == COMA_BF16 && conv_mfma_wgrad_supported(d, x, dy)) ? 2 : 1;
+}
+
+// conv forward + the statistics of the following BatchNorm(train)/InstanceNorm in one pass where the kernel
+// family supports it (epilogue-fused partial sums), otherwise conv followed by the stand-alone statistics pass.
+extern "C" int coma_conv_fwd_norm_stats(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
+                                        const float* bias, const coma_tensor* y, int32_t mode, float eps, float* mean,
+                                        float* rstd, float* running_mean, float* running_var, float momentum, void* ws,
+                                        size_t ws_bytes, void* stream) {
+  if (int rc = conv_check(d, x, y)) return rc;
+  COMA_CHECK(wk && mean && rstd && ws && ws_bytes >= coma_norm_ws_bytes(y), "conv_fwd_norm_stats: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (coma_conv_pick_algo(d, x, y) == 2 && wk_dtype == COMA_BF16) {
+    int chunks = 0;
+    const int inst = mode == COMA_NORM_INSTANCE;
+    if (int rc = conv_mfma_fwd(d, x, wk, bias, y, s, (double2*)ws, inst, &chunks)) return rc;
+    if (chunks > 0) {
+      const int G = inst ? y->B : 1;
+      const int64_t R = inst ? t_vox(y) : t_vox(y) * y->B;
+      return norm_stats_finalize((const double2*)ws, chunks, G, y->C, R, eps, mean, rstd, running_mean, running_var,
+                                 momentum, s);
+    }
+  } else {
+    if (int rc = coma_conv_fwd(d, x, wk, wk_dtype, bias, y, stream)) return rc;
+  }
+  return coma_norm_stats(y, mode, eps, mean, rstd, running_mean, running_var, momentum, ws, ws_bytes, stream);
 }
 
 extern "C" size_t coma_conv_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {

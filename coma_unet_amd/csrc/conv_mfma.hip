@@ -411,6 +411,8 @@ struct Halo2P {
   const float* bias; int bsb;
   int flip, vecx, vecw;
   int ntx, nty, ntz, ids_total, ids_per_block;
+  double2* stats;      // optional: per-block {sum, sumsq} of the stored outputs, [chunk][G][N]
+  int stats_inst;      // 1: groups = samples (InstanceNorm), 0: one group (BatchNorm)
 };
 
 // CK = channels per LDS row (32, or 16 for the thin full-resolution layers: one MFMA K step per tap);
@@ -507,18 +509,27 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   // first valid tile
   int id = id_begin, tix = 0, tiy = 0, tiz = 0;
   while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
-  if (id >= id_end) return;
+  if (id >= id_end) {        // nothing to do for this block (padding ids): still publish a zero partial
+    if (p.stats && tid < 32 && n0 + tid < p.N) {
+      const int G = p.stats_inst ? gridDim.z : 1;
+      const int chunk = p.stats_inst ? blockIdx.x : blockIdx.x + gridDim.x * b;
+      p.stats[((long)chunk * G + (p.stats_inst ? b : 0)) * p.N + n0 + tid] = make_double2(0.0, 0.0);
+    }
+    return;
+  }
   if (RESIDENT) { load_w(0, 0); store_w(); }
   load_halo(tiz * TZ, tiy * TY, tix * TX, 0);
   if (!RESIDENT) load_w(0, 0);
 
   float bv[4][4];
+  float st_s[4][4], st_q[4][4];     // fused norm statistics of this lane's 16 channels (stored values)
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = n0 + 8 * g4 + 4 * fh + q;
       bv[g4][q] = (p.bias && n < p.N) ? p.bias[b * p.bsb + n] : 0.f;
+      st_s[g4][q] = 0.f; st_q[g4][q] = 0.f;
     }
 
   while (id < id_end) {
@@ -592,7 +603,11 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
         for (int g4 = 0; g4 < 4; ++g4) {
           bf16_t o[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = static_cast<bf16_t>(acc[i][g4 * 4 + q] + bv[g4][q]);
+          for (int q = 0; q < 4; ++q) {
+            o[q] = static_cast<bf16_t>(acc[i][g4 * 4 + q] + bv[g4][q]);
+            const float r = static_cast<float>(o[q]);
+            st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]);
+          }
           if (n0 + 8 * g4 + 4 * fh + 3 < p.N) *reinterpret_cast<uint2*>(dst + 8 * g4) = *reinterpret_cast<uint2*>(o);
           else {
 #pragma unroll
@@ -602,6 +617,29 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
       }
     }
     id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
+  }
+  // ---- fused statistics: lanes -> wave (butterfly over the 32 voxel lanes) -> block (LDS) -> partial[chunk] ----
+  if (p.stats) {
+    __syncthreads();                                  // LDS images are dead; reuse the front as a [4 waves][32 ch][2] table
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = st_s[g4][q], c = st_q[g4][q];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+        if (fr == 0) { red[(wid * 32 + 8 * g4 + 4 * fh + q) * 2] = a; red[(wid * 32 + 8 * g4 + 4 * fh + q) * 2 + 1] = c; }
+      }
+    __syncthreads();
+    if (tid < 32 && n0 + tid < p.N) {
+      double a = 0.0, c = 0.0;
+      for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
+      const int G = p.stats_inst ? gridDim.z : 1;
+      const int g = p.stats_inst ? b : 0;
+      const int chunk = p.stats_inst ? blockIdx.x : blockIdx.x + gridDim.x * b;
+      p.stats[((long)chunk * G + g) * p.N + n0 + tid] = make_double2(a, c);
+    }
   }
 }
 
@@ -652,8 +690,11 @@ static int launch_halo(const HaloP& p0, int B, hipStream_t s) {
   return 0;
 }
 
+// stats != NULL requests fused {sum, sumsq} partials; *stats_chunks receives the number of chunks written, or stays
+// 0 when the selected kernel variant cannot fuse them (the caller then runs the stand-alone statistics pass).
 static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
-                          const coma_tensor* y, hipStream_t s) {
+                          const coma_tensor* y, hipStream_t s, double2* stats = nullptr, int stats_inst = 0,
+                          int* stats_chunks = nullptr) {
   HaloP p;
   p.x = (const bf16_t*)x->data; p.ldx = (int)x->ld; p.sbx = x->sb; p.D = x->D; p.H = x->H; p.W = x->W; p.C = x->C;
   p.y = (bf16_t*)y->data; p.ldy = (int)y->ld; p.sby = y->sb; p.N = y->C;
@@ -670,6 +711,7 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     q.x = p.x; q.ldx = p.ldx; q.sbx = p.sbx; q.D = p.D; q.H = p.H; q.W = p.W; q.C = p.C;
     q.y = p.y; q.ldy = p.ldy; q.sby = p.sby; q.N = p.N; q.w = p.w; q.wsb = p.wsb; q.bias = p.bias; q.bsb = p.bsb;
     q.flip = p.flip; q.vecx = p.vecx; q.vecw = p.vecw;
+    q.stats = nullptr; q.stats_inst = stats_inst;
     q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
     q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
     const int nblk_n = (q.N + 31) / 32;
@@ -679,6 +721,10 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     q.ids_per_block = (q.ids_total + gx - 1) / gx;
     gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
     dim3 grid((unsigned)gx, (unsigned)nblk_n, (unsigned)x->B);
+    if (stats && gx * (stats_inst ? 1 : x->B) <= 1024 / (stats_inst ? x->B : 1)) {
+      q.stats = stats;
+      *stats_chunks = stats_inst ? gx : gx * x->B;
+    }
     constexpr int HV2 = 34 * 6 * 4;
     const bool resident = thin || q.C == 32;
     const size_t lds = thin ? (size_t)(HV2 + 27 * 32) * 48 : (size_t)HV2 * 80 + (size_t)(resident ? 27 : 9) * 32 * 80;
@@ -711,8 +757,8 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
 }
 
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
-                  const coma_tensor* y, hipStream_t s) {
-  if (halo_ok(d, x, y)) return conv_mfma_halo(d, x, wk, bias, y, s);
+                  const coma_tensor* y, hipStream_t s, double2* stats, int stats_inst, int* stats_chunks) {
+  if (halo_ok(d, x, y)) return conv_mfma_halo(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
   COMA_CHECK(aligned16(wk) && aligned16(x->data), "conv_mfma: operands must be 16-byte aligned");
   GatherP p;
   p.x = (const bf16_t*)x->data; p.ldx = (int)x->ld; p.sbx = x->sb; p.Di = x->D; p.Hi = x->H; p.Wi = x->W; p.C = x->C;
@@ -1111,14 +1157,14 @@ static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const
   const size_t lds = (size_t)(256 + 816) * 64;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr = true;
   }
   const bool vec = p.vec_n && p.vec_c && p.N % 8 == 0 && p.C % 8 == 0;
   const dim3 grid((unsigned)chunks, (unsigned)pairs, (unsigned)x->B);
   if (vec) hipLaunchKernelGGL((conv_mfma_wgrad2_k<1, 2>), grid, dim3(256), lds, s, p);
-  else hipLaunchKernelGGL((conv_mfma_wgrad2_k<0, 1>), grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL((conv_mfma_wgrad2_k<0, 2>), grid, dim3(256), lds, s, p);
   COMA_LAUNCH_CHECK();
   return 0;
 }

@@ -303,6 +303,15 @@ extern "C" int coma_norm_stats(const coma_tensor* x, int32_t mode, float eps, fl
   return 0;
 }
 
+int norm_stats_finalize(const double2* partial, int nchunks, int G, int C, int64_t R, float eps, float* mean, float* rstd,
+                        float* running_mean, float* running_var, float momentum, hipStream_t s) {
+  const int n = G * C;
+  hipLaunchKernelGGL(stats_finalize_k, dim3((n + 3) / 4), dim3(256), 0, s, partial, nchunks, G, C, R, eps, mean, rstd,
+                     running_mean, running_var, momentum);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int coma_spatial_mean(const coma_tensor* x, float* out, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   RowsP p;

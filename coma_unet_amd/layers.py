@@ -60,7 +60,7 @@ class ADN(nn.Module):
                         self.training, out)
 
 
-def norm_act(cfg, x, bn, mode, act, slope, training, out=None):
+def _norm_params(cfg, bn, training):
     gamma = beta = rmean = rvar = None
     momentum, eps = 0.1, 1e-5
     if bn is not None:
@@ -70,18 +70,36 @@ def norm_act(cfg, x, bn, mode, act, slope, training, out=None):
         momentum = 1.0 - (1.0 - bn.momentum) ** k     # k identical updates folded into one
         if training:
             bn.num_batches_tracked += k
+    return gamma, beta, rmean, rvar, momentum, eps
+
+
+def norm_act(cfg, x, bn, mode, act, slope, training, out=None, pre=None):
+    gamma, beta, rmean, rvar, momentum, eps = _norm_params(cfg, bn, training) if pre is None else \
+        ((bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.1, bn.eps) if bn is not None else (None,) * 4 + (0.1, 1e-5))
     return ops.NormAct.apply(x, gamma, beta, slope, rmean, rvar, mode, act, momentum, eps, training,
-                             Out(out) if out is not None else None)
+                             Out(out) if out is not None else None, pre)
 
 
-def conv_plain(cfg, x, conv: nn.Module, ksize, stride, transposed, out=None):
+def conv_norm_act(cfg, x, conv_fn, adn, out=None):
+    """conv -> ADN with the norm statistics coming out of the conv pass (MONAI Convolution / CondConvolution)."""
+    bn = adn.N if adn.mode == L.NORM_BATCH else None
+    slope = adn.A.weight if adn.act_name in ("prelu", "prelu_relu") else None
+    if adn.mode == L.NORM_BATCH and not adn.training:     # eval: running statistics, plain conv
+        return norm_act(cfg, conv_fn(None), bn, adn.mode, _ACTS[adn.act_name], slope, False, out)
+    _g, _b, rmean, rvar, momentum, eps = _norm_params(cfg, bn, adn.training)
+    upd = adn.training and bn is not None
+    y, mean, rstd = conv_fn((adn.mode, eps, rmean if upd else None, rvar if upd else None, momentum))
+    return norm_act(cfg, y, bn, adn.mode, _ACTS[adn.act_name], slope, adn.training, out, pre=(mean, rstd))
+
+
+def conv_plain(cfg, x, conv: nn.Module, ksize, stride, transposed, out=None, norm=None):
     """nn.Conv3d / nn.ConvTranspose3d semantics with shared weights."""
     n_out = conv.weight.shape[1] if transposed else conv.weight.shape[0]
     a_f, a_d = ops.pick_algo(x.shape, x.dtype, n_out, ksize, stride, transposed, False, x.device, cfg.conv_algo)
     need_dx = x.requires_grad
     wk_f, wk_d = ops.PrepWeights.apply(conv.weight, None, transposed, _wdtype(a_f), _wdtype(a_d) if need_dx else None)
     return ops.Conv.apply(x, wk_f, wk_d, conv.bias, ksize, stride, transposed, False, cfg.conv_algo,
-                          Out(out) if out is not None else None)
+                          Out(out) if out is not None else None, norm)
 
 
 class Convolution(nn.Module):
@@ -105,8 +123,8 @@ class Convolution(nn.Module):
     def forward(self, x, out=None):
         if self.adn is None:
             return conv_plain(self.cfg, x, self.conv, self.k, self.s, self.transposed, out)
-        y = conv_plain(self.cfg, x, self.conv, self.k, self.s, self.transposed)
-        return self.adn(y, out)
+        return conv_norm_act(self.cfg, x, lambda norm: conv_plain(self.cfg, x, self.conv, self.k, self.s, self.transposed,
+                                                                  None, norm), self.adn, out)
 
 
 class MonaiConvBlock(nn.Module):
@@ -142,7 +160,7 @@ class CondConv3d(nn.Module):
         nn.init.uniform_(self.bias, -1.0 / fan_in ** 0.5, 1.0 / fan_in ** 0.5)
 
 
-def conv_cond(cfg, x, cc: CondConv3d, covariate, out=None):
+def conv_cond(cfg, x, cc: CondConv3d, covariate, out=None, norm=None):
     B = x.shape[0]
     cov = covariate.reshape(B, -1).to(device=x.device, dtype=torch.float32)
     assert cov.shape[1] == cc.num_covars, (cov.shape, cc.num_covars)
@@ -154,7 +172,7 @@ def conv_cond(cfg, x, cc: CondConv3d, covariate, out=None):
     need_dx = x.requires_grad
     wk_f, wk_d = ops.PrepWeights.apply(cc.weight, r, cc.is_transposed, _wdtype(a_f), _wdtype(a_d) if need_dx else None)
     return ops.Conv.apply(x, wk_f, wk_d, bias, cc.kernel_size, cc.stride, cc.is_transposed, True, cfg.conv_algo,
-                          Out(out) if out is not None else None)
+                          Out(out) if out is not None else None, norm)
 
 
 class CondConvolution(nn.Module):
@@ -168,7 +186,8 @@ class CondConvolution(nn.Module):
     def forward(self, x, covariate=None, out=None):
         if self.adn is None:
             return conv_cond(self.cfg, x, self.conv, covariate, out)
-        return self.adn(conv_cond(self.cfg, x, self.conv, covariate), out)
+        return conv_norm_act(self.cfg, x, lambda norm: conv_cond(self.cfg, x, self.conv, covariate, None, norm),
+                             self.adn, out)
 
 
 class CondConvBlock(nn.Module):

@@ -143,23 +143,41 @@ def pick_algo(x_shape, x_dtype, n_out, ksize, stride, transposed, per_sample, de
 
 
 class Conv(Function):
+    """y = conv(x).  With `norm` = (mode, eps, running_mean, running_var, momentum) the statistics of the
+    BatchNorm(train)/InstanceNorm that follows are produced in the same pass (epilogue-fused where the kernel
+    supports it) and returned as (y, mean, rstd)."""
+
     @staticmethod
-    def forward(ctx, x, wk_f, wk_d, bias, ksize, stride, transposed, per_sample, algo, out):
+    def forward(ctx, x, wk_f, wk_d, bias, ksize, stride, transposed, per_sample, algo, out, norm=None):
         B, Do, Ho, Wo = conv_out_grid(x.shape, ksize, stride, transposed)
         n = wk_f.shape[2]
         y = out.t if out is not None else _new((B, Do, Ho, Wo, n), x.dtype, x.device)
         form = 1 if transposed else 0
         b = bias.contiguous().float() if bias is not None else None
-        KernelTimer.run("conv_fwd", "mfma" if wk_f.dtype == torch.bfloat16 else "direct",
-                        conv_flops(x.shape, y.shape, ksize, stride),
-                        lambda: check(lib.coma_conv_fwd(_desc(ksize, stride, form, per_sample, algo), ct(x), ptr(wk_f),
-                                                        L.dtype_code(wk_f.dtype), ptr(b), ct(y), L.stream()), "coma_conv_fwd"))
+        kind = "mfma" if wk_f.dtype == torch.bfloat16 else "direct"
+        d = _desc(ksize, stride, form, per_sample, algo)
         ctx.save_for_backward(x, wk_d)
         ctx.meta = (ksize, stride, form, per_sample, algo, bias is not None, tuple(wk_f.shape))
-        return y
+        if norm is None:
+            KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
+                            lambda: check(lib.coma_conv_fwd(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), ct(y),
+                                                            L.stream()), "coma_conv_fwd"))
+            return y
+        mode, eps, rmean, rvar, momentum = norm
+        G = B if mode == L.NORM_INSTANCE else 1
+        mean, rstd = _f32((G, n), x.device), _f32((G, n), x.device)
+        cy = ct(y)
+        ws = workspace(lib.coma_norm_ws_bytes(cy), x.device)
+        KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
+                        lambda: check(lib.coma_conv_fwd_norm_stats(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), cy,
+                                                                   mode, eps, ptr(mean), ptr(rstd), ptr(rmean), ptr(rvar),
+                                                                   momentum, ptr(ws), ws.numel(), L.stream()),
+                                      "coma_conv_fwd_norm_stats"))
+        ctx.mark_non_differentiable(mean, rstd)
+        return y, mean, rstd
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x, wk_d = ctx.saved_tensors
         ksize, stride, form, per_sample, algo, has_bias, wshape = ctx.meta
         dx = dwk = dbias = None
@@ -184,7 +202,7 @@ class Conv(Function):
             KernelTimer.run("conv_wgrad", walgo, conv_flops(x.shape, dy.shape, ksize, stride),
                             lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias), ptr(ws), ws.numel(), s),
                                           "coma_conv_wgrad"))
-        return dx, dwk, None, dbias, None, None, None, None, None, None
+        return dx, dwk, None, dbias, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -192,14 +210,16 @@ class Conv(Function):
 # --------------------------------------------------------------------------------------
 class NormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, slope, rmean, rvar, mode, act, momentum, eps, training, out):
+    def forward(ctx, x, gamma, beta, slope, rmean, rvar, mode, act, momentum, eps, training, out, pre=None):
         dev = x.device
         B, C = x.shape[0], x.shape[4]
         G = B if mode == L.NORM_INSTANCE else 1
         cx = ct(x)
         s = L.stream()
         use_batch_stats = training or mode == L.NORM_INSTANCE
-        if use_batch_stats:
+        if pre is not None:          # statistics already produced by the conv that wrote x
+            mean, rstd = pre
+        elif use_batch_stats:
             mean, rstd = _f32((G, C), dev), _f32((G, C), dev)
             ws = workspace(lib.coma_norm_ws_bytes(cx), dev)
             upd = rmean is not None and training
@@ -232,7 +252,7 @@ class NormAct(Function):
         check(lib.coma_norm_act_bwd(cx, ct(dy), mode, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(slope),
                                     ct(dx), ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(ws), ws.numel(), L.stream()),
               "coma_norm_act_bwd")
-        return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------

@@ -96,6 +96,13 @@ int coma_weight_prep_bwd(const float* dwk, const float* master, const float* r, 
 int coma_conv_pick_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
                   int32_t wk_dtype, const float* bias, const coma_tensor* y, void* stream);
+/* conv forward + statistics of the BatchNorm(train)/InstanceNorm that follows it (MONAI Convolution =
+ * conv -> ADN): the partial sums come out of the conv epilogue where the kernel supports it, so the conv
+ * output is not re-read.  Arguments as coma_conv_fwd + coma_norm_stats (ws >= coma_norm_ws_bytes(y)).   */
+int coma_conv_fwd_norm_stats(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
+                             const float* bias, const coma_tensor* y, int32_t mode, float eps, float* mean,
+                             float* rstd, float* running_mean, float* running_var, float momentum,
+                             void* ws, size_t ws_bytes, void* stream);
 /* dwk[b][tap][n][c] (=) sum_m dy[m][n] * x[pos(m,tap)][c]; fp32; batch-summed when
  * !per_sample_w.  dbias[b][n] (=) sum_m dy[m][n] (may be NULL).                     */
 int coma_conv_wgrad_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
