@@ -411,6 +411,7 @@ struct Halo2P {
   const float* bias; int bsb;
   int flip, vecx, vecw;
   int ntx, nty, ntz, ids_total, ids_per_block;
+  int st8;             // output rows allow aligned 8-byte (4-channel) stores
   double2* stats;      // optional: per-block {sum, sumsq} of the stored outputs, [chunk][G][N]
   int stats_inst;      // 1: groups = samples (InstanceNorm), 0: one group (BatchNorm)
 };
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
             const float r = static_cast<float>(o[q]);
             st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]);
           }
-          if (n0 + 8 * g4 + 4 * fh + 3 < p.N) *reinterpret_cast<uint2*>(dst + 8 * g4) = *reinterpret_cast<uint2*>(o);
+          if (p.st8 && n0 + 8 * g4 + 4 * fh + 3 < p.N) *reinterpret_cast<uint2*>(dst + 8 * g4) = *reinterpret_cast<uint2*>(o);
           else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (n0 + 8 * g4 + 4 * fh + q < p.N) dst[8 * g4 + q] = o[q];
@@ -643,6 +644,87 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   }
 }
 
+// =====================================================================================
+// conv_mfma_pw_k -- 1x1x1 convolution for small channel counts (8 <= C <= 64, N <= 64): the attention
+// gate's W_g / W_x (C -> C/2) and their data-gradients at full resolution.  HBM-bound: no LDS at all --
+// the weight fragments live in registers for the whole kernel, each lane streams 16-byte channel chunks
+// of its voxel straight into the MFMA B operand (weights x voxels orientation), and stores four
+// channels per 8-byte write.  Replaces the VALU direct kernel (16 x 32 FMAs per voxel) on these layers.
+// =====================================================================================
+struct PwP {
+  const bf16_t* x; int ldx; long sbx; long V; int C;
+  bf16_t* y; int ldy; long sby; int N;
+  const bf16_t* w; long wsb;
+  const float* bias; int bsb;
+  int st8;
+};
+
+template <int KS, int NT>   // KS = ceil(C / 16) K steps, NT = ceil(N / 32) row tiles
+__global__ __launch_bounds__(256) void conv_mfma_pw_k(PwP p) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int b = blockIdx.y;
+  const bf16_t* xb = p.x + (long)b * p.sbx;
+  const bf16_t* wb = p.w + (long)b * p.wsb;
+  bf16_t* yb = p.y + (long)b * p.sby;
+  // weight fragments: lane (row n = fr, half fh) holds w[n][16 ks + 8 fh .. +8]
+  bf16x8_t wf[NT][KS];
+  float bv[NT][4][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = j * 32 + fr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 16 + fh * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n < p.N && c < p.C) v = *reinterpret_cast<const uint4*>(wb + (long)n * p.C + c);
+      wf[j][ks] = *reinterpret_cast<const bf16x8_t*>(&v);
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nn = j * 32 + 8 * g4 + 4 * fh + q;
+        bv[j][g4][q] = (p.bias && nn < p.N) ? p.bias[b * p.bsb + nn] : 0.f;
+      }
+  }
+  const long mtiles = (p.V + 31) / 32;
+  for (long mt = (long)blockIdx.x * 4 + wid; mt < mtiles; mt += (long)gridDim.x * 4) {
+    const long v = mt * 32 + fr;
+    const bool live = v < p.V;
+    bf16x8_t xf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 16 + fh * 8;
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (live && c < p.C) t = *reinterpret_cast<const uint4*>(xb + v * p.ldx + c);
+      xf[ks] = *reinterpret_cast<const bf16x8_t*>(&t);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      f32x16_t acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][ks], xf[ks], acc, 0, 0, 0);
+      if (live) {
+        bf16_t* dst = yb + v * p.ldy + j * 32 + 4 * fh;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          bf16_t o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = static_cast<bf16_t>(acc[g4 * 4 + q] + bv[j][g4][q]);
+          if (p.st8 && j * 32 + 8 * g4 + 4 * fh + 3 < p.N) *reinterpret_cast<uint2*>(dst + 8 * g4) = *reinterpret_cast<uint2*>(o);
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (j * 32 + 8 * g4 + 4 * fh + q < p.N) dst[8 * g4 + q] = o[q];
+          }
+        }
+      }
+    }
+  }
+}
+
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 static bool halo_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
@@ -651,10 +733,16 @@ static bool halo_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_te
          (x->C >= 8 || y->C >= 8 || x->C * y->C >= 8);
 }
 
+static bool pw_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  return d->ksize == 1 && d->stride == 1 && x->C >= 8 && x->C <= 64 && x->C % 8 == 0 && y->C >= 4 && y->C <= 64 &&
+         x->ld % 8 == 0 && x->sb % 8 == 0 && (!x->data || aligned16(x->data)) && t_vox(x) >= 4096;
+}
+
 bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (x->dtype != COMA_BF16 || y->dtype != COMA_BF16) return false;
   if ((long)t_vox(x) * x->ld >= (1L << 31) || (long)t_vox(y) * y->ld >= (1L << 31)) return false;
   if (halo_ok(d, x, y)) return true;
+  if (pw_ok(d, x, y)) return true;
   if (x->C % 32 || y->C % 32) return false;
   if (x->ld % 8 || y->ld % 8 || x->sb % 8 || y->sb % 8) return false;
   if (x->data && !aligned16(x->data)) return false;
@@ -706,12 +794,13 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
   const bool thin = x->C <= 16;
   const int lx = x->W >= 32 ? 5 : (x->W >= 16 ? 4 : 3);
   const bool vec = p.vecx && p.vecw && x->C % 32 == 0;
-  if (lx == 5 && y->ld % 4 == 0 && (((uintptr_t)y->data) & 7) == 0 && (thin || vec)) {
+  if (lx == 5 && (thin || vec)) {
     Halo2P q;
     q.x = p.x; q.ldx = p.ldx; q.sbx = p.sbx; q.D = p.D; q.H = p.H; q.W = p.W; q.C = p.C;
     q.y = p.y; q.ldy = p.ldy; q.sby = p.sby; q.N = p.N; q.w = p.w; q.wsb = p.wsb; q.bias = p.bias; q.bsb = p.bsb;
     q.flip = p.flip; q.vecx = p.vecx; q.vecw = p.vecw;
     q.stats = nullptr; q.stats_inst = stats_inst;
+    q.st8 = y->ld % 4 == 0 && y->sb % 4 == 0 && (((uintptr_t)y->data) & 7) == 0;
     q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
     q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
     const int nblk_n = (q.N + 31) / 32;
@@ -759,6 +848,25 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                   const coma_tensor* y, hipStream_t s, double2* stats, int stats_inst, int* stats_chunks) {
   if (halo_ok(d, x, y)) return conv_mfma_halo(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
+  if (pw_ok(d, x, y) && !(x->C % 32 == 0 && y->C % 32 == 0 && x->C * y->C > 64 * 32)) {
+    COMA_CHECK(aligned16(wk), "conv_mfma: weights must be 16-byte aligned");
+    PwP q;
+    q.x = (const bf16_t*)x->data; q.ldx = (int)x->ld; q.sbx = x->sb; q.V = t_vox(x); q.C = x->C;
+    q.y = (bf16_t*)y->data; q.ldy = (int)y->ld; q.sby = y->sb; q.N = y->C;
+    q.w = (const bf16_t*)wk; q.wsb = d->per_sample_w ? (long)y->C * x->C : 0;
+    q.bias = bias; q.bsb = d->per_sample_w ? y->C : 0;
+    q.st8 = y->ld % 4 == 0 && y->sb % 4 == 0 && (((uintptr_t)y->data) & 7) == 0;
+    const int ks = (x->C + 15) / 16, nt = (y->C + 31) / 32;
+    long nb = ((q.V + 31) / 32 + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    dim3 grid((unsigned)nb, (unsigned)x->B);
+#define PWL(K_, N_) hipLaunchKernelGGL((conv_mfma_pw_k<K_, N_>), grid, dim3(256), 0, s, q)
+    if (nt == 1) { if (ks == 1) PWL(1, 1); else if (ks == 2) PWL(2, 1); else if (ks == 3) PWL(3, 1); else PWL(4, 1); }
+    else { if (ks == 1) PWL(1, 2); else if (ks == 2) PWL(2, 2); else if (ks == 3) PWL(3, 2); else PWL(4, 2); }
+#undef PWL
+    COMA_LAUNCH_CHECK();
+    return 0;
+  }
   COMA_CHECK(aligned16(wk) && aligned16(x->data), "conv_mfma: operands must be 16-byte aligned");
   GatherP p;
   p.x = (const bf16_t*)x->data; p.ldx = (int)x->ld; p.sbx = x->sb; p.Di = x->D; p.Hi = x->H; p.Wi = x->W; p.C = x->C;
@@ -987,11 +1095,12 @@ struct Wgrad2P {
 // One tile's MFMAs for the calling wave.  toff[t] = LDS byte offset of the wave's t-th tap (wave-uniform
 // scalars, so each gathered read costs one v_add with an SGPR operand; K-step offsets are scalars too and
 // the +4-voxel second read is an immediate).
+template <int HX, int HY>
 __device__ __forceinline__ void wgrad2_tile(const char* Dt, const char* Gt, int lane_d, int lane_g, const int (&toff)[7],
-                                            int ntap, f32x16_t (&acc)[7]) {
-  constexpr int HX = 34, HY = 6, PD = 64, PG = 64;
+                                            int ntap, f32x16_t (&acc)[7], int ks0, int ksd) {
+  constexpr int PD = 64, PG = 64;
 #pragma unroll 2
-  for (int ks = 0; ks < 16; ++ks) {
+  for (int ks = ks0; ks < 16; ks += ksd) {
     // K step ks = 16 consecutive x of row (z = ks >> 3, y = (ks >> 1) & 3), x half = ks & 1
     const int z = ks >> 3, y = (ks >> 1) & 3, xh = ks & 1;
     const char* dp = Dt + lane_d + ((z * 4 + y) * 32 + xh * 16) * PD;
@@ -1011,9 +1120,12 @@ __device__ __forceinline__ void wgrad2_tile(const char* Dt, const char* Gt, int 
   }
 }
 
-template <int VEC, int OCC>   // VEC=1: every staged piece is a legal, fully valid 16-byte load; OCC = blocks per CU
+// VEC=1: every staged piece is a legal, fully valid 16-byte load; OCC = blocks per CU; K = kernel size (3 or 1:
+// for 1x1x1 there is one tap and the four waves share it by K step instead of by tap).
+template <int VEC, int OCC, int K>
 __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
-  constexpr int TX = 32, TY = 4, TZ = 2, TM = TX * TY * TZ, HX = 34, HY = 6, HZ = 4, HV = HX * HY * HZ;
+  constexpr int PADK = (K - 1) / 2;
+  constexpr int TX = 32, TY = 4, TZ = 2, TM = TX * TY * TZ, HX = TX + K - 1, HY = TY + K - 1, HZ = TZ + K - 1, HV = HX * HY * HZ;
   constexpr int NDP = TM * 4, NGP = HV * 4;                     // 16-byte pieces (dense, halo)
   constexpr int DIT = NDP / 256, GIT = (NGP + 255) / 256;        // 4 and 13 per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1049,9 +1161,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int tap = wid + 4 * t;
-    toff[t] = __builtin_amdgcn_readfirstlane((((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64);
+    toff[t] = K == 1 ? 0 : __builtin_amdgcn_readfirstlane((((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64);
   }
-  const int ntap = wid == 3 ? 6 : 7;
+  const int ntap = K == 1 ? 1 : (wid == 3 ? 6 : 7);
 
   const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * p.tiles_per_block;
   int tile_end = tile_begin + p.tiles_per_block;
@@ -1078,7 +1190,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
       for (int it = 0; it < GIT; ++it) {
         const int row = (tid >> 2) + 64 * it;
         const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
-        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const int gz = z0 - PADK + hz, gy = y0 - PADK + hy, gx = x0 - PADK + hx;
         gv[it] = make_uint4(0, 0, 0, 0);
         if (row < HV && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
           const bf16_t* src = xb + (unsigned)(((gz * p.H + gy) * p.W + gx) * p.ldc + ch * 8);
@@ -1109,7 +1221,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
     store_tile();
     __syncthreads();
     if (OCC == 1) { if (nt < tile_end) load_tile(ntix * TX, ntiy * TY, ntiz * TZ); }   // prefetch under the MFMAs
-    wgrad2_tile(Dt, Gt, lane_d, lane_g, toff, ntap, acc);
+    wgrad2_tile<HX, HY>(Dt, Gt, lane_d, lane_g, toff, ntap, acc, K == 1 ? wid : 0, K == 1 ? 4 : 1);
     if (OCC != 1) { if (nt < tile_end) load_tile(ntix * TX, ntiy * TY, ntiz * TZ); }   // the co-resident block covers this latency
     tile = nt;
   }
@@ -1118,8 +1230,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
   const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
-    const int tap = wid + 4 * t;
-    if (tap < 27) {
+    const int tap = K == 1 ? 0 : wid + 4 * t;
+    if (t < ntap) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * fh;
@@ -1131,7 +1243,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
 }
 
 static bool wgrad2_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
-  return d->form == 0 && d->stride == 1 && d->ksize == 3 && x->dtype == COMA_BF16 && dy->dtype == COMA_BF16 &&
+  return d->form == 0 && d->stride == 1 && (d->ksize == 3 || d->ksize == 1) && x->dtype == COMA_BF16 && dy->dtype == COMA_BF16 &&
          x->W >= 32 && (long)t_vox(x) * x->ld < (1L << 31) && (long)t_vox(dy) * dy->ld < (1L << 31);
 }
 
@@ -1151,20 +1263,26 @@ static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const
   if (chunks > p.tiles_total) chunks = p.tiles_total;
   p.tiles_per_block = (p.tiles_total + chunks - 1) / chunks;
   chunks = (p.tiles_total + p.tiles_per_block - 1) / p.tiles_per_block;
-  p.dwk = dwk; p.wsb = d->per_sample_w ? 27L * p.N * p.C : 0;
-  const long wsz = 27L * p.N * p.C * (d->per_sample_w ? x->B : 1);
+  const long taps = (long)d->ksize * d->ksize * d->ksize;
+  p.dwk = dwk; p.wsb = d->per_sample_w ? taps * p.N * p.C : 0;
+  const long wsz = taps * p.N * p.C * (d->per_sample_w ? x->B : 1);
   if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
-  const size_t lds = (size_t)(256 + 816) * 64;
+  const size_t lds = (size_t)(256 + (d->ksize == 3 ? 816 : 256)) * 64;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<0, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr = true;
   }
   const bool vec = p.vec_n && p.vec_c && p.N % 8 == 0 && p.C % 8 == 0;
   const dim3 grid((unsigned)chunks, (unsigned)pairs, (unsigned)x->B);
-  if (vec) hipLaunchKernelGGL((conv_mfma_wgrad2_k<1, 2>), grid, dim3(256), lds, s, p);
-  else hipLaunchKernelGGL((conv_mfma_wgrad2_k<0, 2>), grid, dim3(256), lds, s, p);
+  if (d->ksize == 1) {
+    if (vec) hipLaunchKernelGGL((conv_mfma_wgrad2_k<1, 2, 1>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_mfma_wgrad2_k<0, 2, 1>), grid, dim3(256), lds, s, p);
+  } else {
+    if (vec) hipLaunchKernelGGL((conv_mfma_wgrad2_k<1, 2, 3>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_mfma_wgrad2_k<0, 2, 3>), grid, dim3(256), lds, s, p);
+  }
   COMA_LAUNCH_CHECK();
   return 0;
 }

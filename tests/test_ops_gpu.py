@@ -296,6 +296,9 @@ THIN_CASES = [
     (16, 16, 3, 1, False, (4, 5, 18)), (16, 1, 3, 1, False, (5, 5, 17)), (2, 8, 3, 1, False, (3, 4, 40)),
     (32, 16, 1, 1, False, (6, 7, 33)), (256, 128, 1, 1, False, (4, 4, 4)), (2, 1, 1, 1, False, (4, 4, 20)),
     (48, 40, 3, 1, False, (3, 5, 9)),
+    # pointwise MFMA kernel (>= 4096 voxels): gate W_g / W_x shapes and their data-gradients
+    (32, 16, 1, 1, False, (17, 16, 19)), (16, 32, 1, 1, False, (16, 16, 17)), (64, 32, 1, 1, False, (16, 17, 16)),
+    (24, 40, 1, 1, False, (16, 16, 16)), (16, 8, 1, 1, False, (18, 16, 16)),
 ]
 
 
