@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_VALU_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBPS = 8000.0
 UNET_TFLOP_PER_VOLUME_128 = 2.340  # BASELINE.md section 2 (U-Net fwd+bwd, 128^3)
 
 
@@ -65,6 +66,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("COMA_BENCH_ONE_DEVICE"):      # rehearsal of the N > 1 path on a 1-GPU box (all ranks on cuda:0)
+        local = 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -73,7 +76,11 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("COMA_DIST_BACKEND", "nccl")      # "gloo" only for rehearsing N > 1 on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import coma_unet_amd as cu
     from coma_unet_amd import ops
@@ -102,13 +109,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # One GPU: the whole step is ONE captured hipGraph (same kernels, no host launch gaps).  N > 1 keeps the
-    # eager step so that the bucketed all-reduce is issued from backward hooks and overlaps it.
-    use_graph = world == 1 and not args.no_graph
+    # The step is replayed from a captured hipGraph (same kernels, no host launch gaps): one graph for the whole
+    # step on one GPU; with N > 1 the graph holds forward + backward and the bucketed RCCL all-reduce + AdamW
+    # follow it.  --no-graph runs the eager step (N > 1: all-reduce issued from backward hooks, overlapped).
+    use_graph = not args.no_graph
+    graph_note = None
     if use_graph:
-        step_fn = GraphedTrainStep(model, crit, opt, batch, warmup=max(args.warmup, 2))
-        run_step = lambda: step_fn()[0]
-    else:
+        try:
+            step_fn = GraphedTrainStep(model, crit, opt, batch, warmup=max(args.warmup, 2), reducer=reducer)
+            run_step = lambda: step_fn()[0]
+        except Exception as e:      # never lose the measurement to a capture problem: fall back to the eager step
+            graph_note = f"graph capture failed ({type(e).__name__}: {e}); eager step used"
+            print(graph_note, file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            use_graph = False
+            reducer = GradReducer(opt) if world > 1 else None
+    if not use_graph:
         for _ in range(args.warmup):
             train_step(model, crit, opt, batch, reducer)
         run_step = lambda: train_step(model, crit, opt, batch, reducer)[0]
@@ -146,17 +162,23 @@ def main():
         roof = None
         kernels = {}
         if summ:
-            for (kind, algo), (n, ms, fl) in sorted(summ.items()):
+            for (kind, algo), (n, ms, fl, by) in sorted(summ.items()):
                 kernels[f"{kind}/{algo}"] = {"launches": n, "ms_total": round(ms, 3),
-                                             "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None}
-            (kind, algo), (n, ms, fl) = max(summ.items(), key=lambda kv: kv[1][1])
-            peak = MFMA_BF16_PEAK_TFLOPS if algo == "mfma" else FP32_VALU_PEAK_TFLOPS
-            ach = fl / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": f"{kind}/{algo}", "achieved": round(ach, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                    "launches": n, "avg_launch_ms": round(ms / n, 4),
-                    "step_tflops_all_convs": round(sum(v[2] for v in summ.values()) / timer_steps / 1e12, 3),
-                    "measured": timer_note}
+                                             "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+                                             "alg_GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+            (kind, algo), (n, ms, fl, by) = max(summ.items(), key=lambda kv: kv[1][1])
+            common = {"kernel": f"{kind}/{algo}", "traffic": None, "launches": n, "avg_launch_ms": round(ms / n, 4),
+                      "step_tflops_all_convs": round(sum(v[2] for v in summ.values()) / timer_steps / 1e12, 3),
+                      "measured": timer_note}
+            if algo == "mfma-thin":     # zero-padded thin layers: bytes, not FLOPs, are the algorithmic work
+                ach = by / (ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBPS, 4), **common}
+            else:
+                peak = MFMA_BF16_PEAK_TFLOPS if algo.startswith("mfma") else FP32_VALU_PEAK_TFLOPS
+                ach = fl / (ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), **common}
         line = {
             "metric": "volumes/sec (train fwd+bwd) at 128^3 bf16", "value": round(value, 4), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,9 +187,10 @@ def main():
             "config": {"workload": f"CoMA-UNet train step (fwd + RoiMSE/RnC loss + bwd + all-reduce + AdamW), "
                                    f"{args.size}^3 volumes, batch {args.batch}/GPU, 6-dim covariates (BASELINE configs[3])",
                        "global_batch": args.batch * world, "volume": list(S), "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay of the whole step" if use_graph else "eager (hook-driven all-reduce overlap)",
+                       "launch": ("hipGraph replay" + (" of fwd+bwd, then bucketed RCCL all-reduce + AdamW" if world > 1 else " of the whole step"))
+                                 if use_graph else "eager (hook-driven all-reduce overlap)",
                        "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 1)},
-            "loss": round(loss, 4),
+            "loss": round(loss, 4), "note": graph_note,
             "unet_tflops_per_s": round(value * UNET_TFLOP_PER_VOLUME_128 * (args.size / 128.0) ** 3, 2),
             "roofline": roof, "conv_kernels": kernels,
         }

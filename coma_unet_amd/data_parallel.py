@@ -100,6 +100,27 @@ class GradReducer:
             for b in self._buckets:
                 b[2] = b[3]
 
+    def reduce_flat(self):
+        """All buckets of the flat gradient buffer at once (no hooks): used when forward+backward are replayed
+        from a hipGraph, where per-parameter hooks do not fire.  Requires the optimizer's flat layout."""
+        if self.world == 1:
+            return
+        opt = self.opt
+        assert opt.built, "reduce_flat needs the flat gradient layout (run two eager steps first)"
+        n = opt.flat_g.numel()
+        works = [dist.all_reduce(opt.flat_g[s:min(s + self.bucket_elems, n)], op=dist.ReduceOp.SUM, group=self.group,
+                                 async_op=True) for s in range(0, n, self.bucket_elems)]
+        for w in works:
+            w.wait()
+        for p in opt.param_groups[0]["params"]:
+            if id(p) not in opt._flat_ids and p.grad is not None:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
     def finish(self):
         """Call after backward, before optimizer.step()."""
         if self.world == 1:

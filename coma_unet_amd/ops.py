@@ -41,19 +41,30 @@ class KernelTimer:
 
     @classmethod
     def summary(cls):
-        """{(kind, algo): (launches, total_ms, total_flops)} -- call after torch.cuda.synchronize()."""
+        """{(kind, algo): (launches, total_ms, total_flops, total_bytes)} -- call after torch.cuda.synchronize().
+        `flops` entries are (flops, algorithmic_bytes) pairs."""
         out = {}
-        for kind, algo, flops, e0, e1 in cls.records:
-            n, ms, fl = out.get((kind, algo), (0, 0.0, 0.0))
-            out[(kind, algo)] = (n + 1, ms + e0.elapsed_time(e1), fl + flops)
+        for kind, algo, fb, e0, e1 in cls.records:
+            fl, by = fb if isinstance(fb, tuple) else (fb, 0.0)
+            n, ms, f0, b0 = out.get((kind, algo), (0, 0.0, 0.0, 0.0))
+            out[(kind, algo)] = (n + 1, ms + e0.elapsed_time(e1), f0 + fl, b0 + by)
         return out
 
 
 def conv_flops(x_shape, y_shape, ksize, stride):
-    """2 * MACs of one gather launch: every (coarse-grid voxel, tap, c, n) combination once."""
+    """(2 * MACs, algorithmic HBM bytes) of one gather launch: every (coarse-grid voxel, tap, c, n) combination
+    once; each operand voxel read once and each result voxel written once (2-byte elements)."""
     vx = x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3]
     vy = y_shape[0] * y_shape[1] * y_shape[2] * y_shape[3]
-    return 2.0 * min(vx, vy) * (ksize ** 3) * x_shape[4] * y_shape[4]
+    return (2.0 * min(vx, vy) * (ksize ** 3) * x_shape[4] * y_shape[4], 2.0 * (vx * x_shape[4] + vy * y_shape[4]))
+
+
+def conv_class(algo_name, cin, cout):
+    """MFMA launches are split into 'thick' (>= 32 channels both sides: MFMA-bound) and 'thin' (zero-padded
+    tiles on the full-resolution 1..16-channel layers: HBM-bound) so the roofline is quoted per regime."""
+    if algo_name != "mfma":
+        return algo_name
+    return "mfma-thick" if min(cin, cout) >= 32 else "mfma-thin"
 
 
 def _new(shape, dtype, device):
@@ -154,7 +165,7 @@ class Conv(Function):
         y = out.t if out is not None else _new((B, Do, Ho, Wo, n), x.dtype, x.device)
         form = 1 if transposed else 0
         b = bias.contiguous().float() if bias is not None else None
-        kind = "mfma" if wk_f.dtype == torch.bfloat16 else "direct"
+        kind = conv_class("mfma" if wk_f.dtype == torch.bfloat16 else "direct", x.shape[4], n)
         d = _desc(ksize, stride, form, per_sample, algo)
         ctx.save_for_backward(x, wk_d)
         ctx.meta = (ksize, stride, form, per_sample, algo, bias is not None, tuple(wk_f.shape))
@@ -185,7 +196,7 @@ class Conv(Function):
         if ctx.needs_input_grad[0]:
             assert wk_d is not None, "data gradient requested but dgrad weights were not prepared"
             dx = torch.empty_like(x) if x.is_contiguous() else _new(x.shape, x.dtype, x.device)
-            KernelTimer.run("conv_dgrad", "mfma" if wk_d.dtype == torch.bfloat16 else "direct",
+            KernelTimer.run("conv_dgrad", conv_class("mfma" if wk_d.dtype == torch.bfloat16 else "direct", dy.shape[4], x.shape[4]),
                             conv_flops(dy.shape, dx.shape, ksize, stride),
                             lambda: check(lib.coma_conv_fwd(_desc(ksize, stride, 1 - form, per_sample, algo), ct(dy),
                                                             ptr(wk_d), L.dtype_code(wk_d.dtype), None, ct(dx), s),
@@ -198,7 +209,7 @@ class Conv(Function):
             dwk = _f32(wshape, x.device)
             if has_bias:
                 dbias = _f32((x.shape[0], wshape[2]) if per_sample else (wshape[2],), x.device)
-            walgo = "mfma" if lib.coma_conv_wgrad_algo(d, cx, cdy) == 2 else "direct"
+            walgo = conv_class("mfma" if lib.coma_conv_wgrad_algo(d, cx, cdy) == 2 else "direct", x.shape[4], dy.shape[4])
             KernelTimer.run("conv_wgrad", walgo, conv_flops(x.shape, dy.shape, ksize, stride),
                             lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias), ptr(ws), ws.numel(), s),
                                           "coma_conv_wgrad"))

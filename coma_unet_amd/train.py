@@ -43,29 +43,39 @@ def train_step(model, criterion, optimizer, batch, reducer: GradReducer = None):
 
 
 class GraphedTrainStep:
-    """The whole step (zero_grad + forward + loss + backward + fused AdamW) captured in ONE hipGraph and
-    replayed: ~450 kernel launches per step collapse into one graph launch, which removes the host launch
-    gaps (the reference's step is launch-bound in the same way on its cuDNN path).  Requirements: a model
-    built with ``static_prompts=True`` (no host read of the covariates), ROI priors passed as a (B,36,2)
-    tensor, fixed shapes.  New data is copied into the static input buffers before each replay.
-    Single-GPU only: the data-parallel path keeps the eager step with hook-driven bucket all-reduce.
+    """The step captured in a hipGraph and replayed: ~450 kernel launches collapse into one graph launch, which
+    removes the host launch gaps (the reference's step is launch-bound in the same way on its cuDNN path).
+    One GPU: zero_grad + forward + loss + backward + fused AdamW are ONE graph.  Data parallel (`reducer`
+    given): the graph holds zero_grad + forward + loss + backward; the bucketed RCCL SUM all-reduce of the
+    flat gradient buffer and the one-kernel AdamW step follow it eagerly (no collective inside the graph).
+    Requirements: a model built with ``static_prompts=True`` (no host read of the covariates), ROI priors
+    passed as a (B,36,2) tensor, fixed shapes.  New data is copied into the static input buffers.
     """
 
-    def __init__(self, model, criterion, optimizer, batch, warmup=3):
+    def __init__(self, model, criterion, optimizer, batch, warmup=3, reducer: GradReducer = None):
         assert getattr(model, "static_prompts", False), "graph capture needs static_prompts=True"
-        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.model, self.criterion, self.optimizer, self.reducer = model, criterion, optimizer, reducer
         self.batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         assert torch.is_tensor(self.batch["roi_pred_dicts"]), "pass ROI priors as a (B, 36, 2) device tensor"
+        if reducer is not None:
+            reducer.overlap = False          # hooks do not fire under replay
+            reducer.remove_hooks()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(warmup, 2)):      # builds the flat optimizer layout, sizes workspaces
-                train_step(model, criterion, optimizer, self.batch)
+                train_step(model, criterion, optimizer, self.batch, reducer)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.losses, self.outputs = train_step(model, criterion, optimizer, self.batch)
+        # thread_local: the RCCL watchdog thread may query events while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            if reducer is None:
+                self.losses, self.outputs = train_step(model, criterion, optimizer, self.batch)
+            else:
+                optimizer.zero_grad()
+                self.losses, self.outputs = forward_loss(model, criterion, self.batch)
+                self.losses[0].backward()
 
     def load(self, batch):
         for k, v in batch.items():
@@ -76,5 +86,9 @@ class GraphedTrainStep:
         if batch is not None:
             self.load(batch)
         self.graph.replay()
-        self.optimizer._flat_step += 1
+        if self.reducer is None:
+            self.optimizer._flat_step += 1
+        else:
+            self.reducer.reduce_flat()
+            self.optimizer.step()
         return self.losses, self.outputs

@@ -222,6 +222,23 @@ def test_rccl_reducer_path_single_rank():
         print("plain", losses[0], "reduced", losses[1])
         for a, r in zip(losses[1], losses[0]):
             assert abs(a - r) <= 1e-3 * abs(r)    # fp32 atomics in the weight-gradient merge are order-dependent
+        # graph-replayed forward+backward followed by the flat all-reduce + AdamW (bench.py's N > 1 mode)
+        from coma_unet_amd.train import GraphedTrainStep
+        torch.manual_seed(3)
+        gm = cu.build_model(volume_shape=S, static_prompts=True).cuda()
+        gm.set_save_attn(None)
+        gm.train(True)
+        opt = make_optimizer(gm, 1e-3)
+        broadcast_module(gm)
+        red = GradReducer(opt, bucket_bytes=8 << 20)
+        red.world = 2
+        gb = dict(b)
+        gb["roi_pred_dicts"] = gm._priors(b["roi_pred_dicts"], 2, torch.device("cuda"))
+        step = GraphedTrainStep(gm, cu.build_reference_criterion(), opt, gb, warmup=2, reducer=red)
+        ls = [float(step()[0][0]) for _ in range(2)]
+        print("graph+reduce", ls)
+        for a, r in zip(ls, losses[0][2:]):
+            assert abs(a - r) <= 1e-3 * abs(r)
     finally:
         dist.destroy_process_group()
 
