@@ -921,7 +921,7 @@ struct WgradP2 {
   unsigned m_hx, m_hxy; // magic multipliers: n / hx == umulhi(n, m_hx), n / (hx*hy) == umulhi(n, m_hxy)
 };
 
-template <int TN, int TC, int FORM>
+template <int TN, int TC, int FORM, int VEC>
 __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
   constexpr int CDB = 32 * (FORM == 0 ? TN : TC);   // dense-side channels per block
   constexpr int CGB = 32 * (FORM == 0 ? TC : TN);   // gathered-side channels per block
@@ -931,7 +931,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
   const int TM = 1 << (p.lx + p.ly + p.lz);
   char* Dt = smem;
   char* Gt = smem + TM * PD;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tap lists live in SGPRs, tap tests are scalar branches
   const int b = blockIdx.z;
   const int nb = blockIdx.y / p.cblocks, cb = blockIdx.y % p.cblocks;
   const int n0 = nb * 32 * TN, c0 = cb * 32 * TC;
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
     const int tap = p.k == 1 ? (t == 0 ? 0 : ntaps) : wid + 4 * t;
     tap_w[t] = tap;
     const int kx = tap % p.k, ky = (tap / p.k) % p.k, kz = tap / (p.k * p.k);
-    toff_w[t] = ((kz * p.hy + ky) * p.hx + kx) * PG;
+    toff_w[t] = __builtin_amdgcn_readfirstlane(((kz * p.hy + ky) * p.hx + kx) * PG);
   }
   // lane roles for the transposed reads
   const int g16 = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
@@ -972,46 +973,60 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
   int tile_end = tile_begin + p.tiles_per_block;
   if (tile_end > p.tiles_total) tile_end = p.tiles_total;
 
-  for (int tile = tile_begin; tile < tile_end; ++tile) {
-    int tix, tiy, tiz;
-    if (!tile_coords(tile, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) continue;   // uniform across the block
-    const int x0 = tix << p.lx, y0 = tiy << p.ly, z0 = tiz << p.lz;
-    __syncthreads();   // previous tile's reads are done
-    // ---- dense tile + gathered halo: loads are issued 8 deep before any is consumed ----
-    constexpr int U = 8;
+  // ---- software pipeline: the next tile's global loads are in flight (registers) while this tile computes ----
+  constexpr int MAXP = 20;                      // 16-byte pieces per thread (host guarantees pieces <= 256 * MAXP)
+  uint4 sv[MAXP];
+  const int ndp = TM * (CDB / 8), ngp = HV * (CGB / 8);
+  auto piece_dst = [&](int piece) -> int {
+    if (piece < ndp) return (piece / (CDB / 8)) * PD + (piece % (CDB / 8)) * 16;
+    const int pg = piece - ndp;
+    return TM * PD + (pg / (CGB / 8)) * PG + (pg % (CGB / 8)) * 16;
+  };
+  auto load_tile = [&](int x0, int y0, int z0) {
     const int bz = z0 * p.stride - p.pad, by = y0 * p.stride - p.pad, bx = x0 * p.stride - p.pad;
-    const int ndp = TM * (CDB / 8), ngp = HV * (CGB / 8);
-    for (int base = tid; base < ndp + ngp; base += 256 * U) {
-      uint4 v[U];
-      int dst[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int piece = base + 256 * u;
-        v[u] = make_uint4(0, 0, 0, 0);
-        dst[u] = -1;
-        if (piece < ndp) {
-          const int row = piece / (CDB / 8), ch = piece % (CDB / 8);
-          const int vx = row & (tx - 1), vy = (row >> p.lx) & (ty - 1), vz = row >> (p.lx + p.ly);
-          const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
-          dst[u] = row * PD + ch * 16;
-          if (gz < p.Mz && gy < p.My && gx < p.Mx && ch * 8 < chd)
-            v[u] = load8(dense + (long)((gz * p.My + gy) * p.Mx + gx) * ldd + ch * 8, chd - ch * 8, vecd);
-        } else if (piece < ndp + ngp) {
-          const int pg = piece - ndp;
-          const int row = pg / (CGB / 8), ch = pg % (CGB / 8);
-          const int q1 = (int)__umulhi((unsigned)row, p.m_hx), hzi = (int)__umulhi((unsigned)row, p.m_hxy);
-          const int hxi = row - q1 * p.hx, hyi = q1 - hzi * p.hy;
-          const int gz = bz + hzi, gy = by + hyi, gx = bx + hxi;
-          dst[u] = TM * PD + row * PG + ch * 16;
-          if ((unsigned)gz < (unsigned)p.Gz && (unsigned)gy < (unsigned)p.Gy && (unsigned)gx < (unsigned)p.Gx && ch * 8 < chg)
-            v[u] = load8(gath + (long)((gz * p.Gy + gy) * p.Gx + gx) * ldg + ch * 8, chg - ch * 8, vecg);
+    for (int u = 0; u < MAXP; ++u) {
+      const int piece = tid + 256 * u;
+      sv[u] = make_uint4(0, 0, 0, 0);
+      if (piece < ndp) {
+        const int row = piece / (CDB / 8), ch = piece % (CDB / 8);
+        const int vx = row & (tx - 1), vy = (row >> p.lx) & (ty - 1), vz = row >> (p.lx + p.ly);
+        const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+        if (gz < p.Mz && gy < p.My && gx < p.Mx && ch * 8 < chd) {
+          const bf16_t* src = dense + (unsigned)(((gz * p.My + gy) * p.Mx + gx) * ldd + ch * 8);
+          sv[u] = VEC ? *reinterpret_cast<const uint4*>(src) : load8(src, chd - ch * 8, vecd);
+        }
+      } else if (piece < ndp + ngp) {
+        const int pg = piece - ndp;
+        const int row = pg / (CGB / 8), ch = pg % (CGB / 8);
+        const int q1 = (int)__umulhi((unsigned)row, p.m_hx), hzi = (int)__umulhi((unsigned)row, p.m_hxy);
+        const int hxi = row - q1 * p.hx, hyi = q1 - hzi * p.hy;
+        const int gz = bz + hzi, gy = by + hyi, gx = bx + hxi;
+        if ((unsigned)gz < (unsigned)p.Gz && (unsigned)gy < (unsigned)p.Gy && (unsigned)gx < (unsigned)p.Gx && ch * 8 < chg) {
+          const bf16_t* src = gath + (unsigned)(((gz * p.Gy + gy) * p.Gx + gx) * ldg + ch * 8);
+          sv[u] = VEC ? *reinterpret_cast<const uint4*>(src) : load8(src, chg - ch * 8, vecg);
         }
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (dst[u] >= 0) *reinterpret_cast<uint4*>(smem + dst[u]) = v[u];
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+      const int piece = tid + 256 * u;
+      if (piece < ndp + ngp) *reinterpret_cast<uint4*>(smem + piece_dst(piece)) = sv[u];
+    }
+  };
+
+  int tile = tile_begin, tix = 0, tiy = 0, tiz = 0;
+  while (tile < tile_end && !tile_coords(tile, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++tile;
+  if (tile < tile_end) load_tile(tix << p.lx, tiy << p.ly, tiz << p.lz);
+  while (tile < tile_end) {
+    int nt = tile + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nt < tile_end && !tile_coords(nt, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nt;
+    __syncthreads();   // previous tile's reads are done
+    store_tile();
     __syncthreads();
+    if (nt < tile_end) load_tile(ntix << p.lx, ntiy << p.ly, ntiz << p.lz);
     // ---- MFMA over the tile's voxels, 16 per K step ----
     const int ksteps = TM >> 4;
     for (int ks = 0; ks < ksteps; ++ks) {
@@ -1051,6 +1066,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
         }
       }
     }
+    tile = nt; tix = ntix; tiy = ntiy; tiz = ntiz;
   }
   // ---- merge into dwk[b][tap][n][c] ----
   float* wout = p.dwk + (long)b * p.wsb;
@@ -1310,31 +1326,35 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   p.vec_c = x->ld % 8 == 0 && x->sb % 8 == 0 && (!x->data || aligned16(x->data));
   pl.tn = (dy->C > 32 && !(x->C > 32 && x->C > dy->C)) ? 2 : 1;
   pl.tc = (pl.tn == 1 && x->C > 32) ? 2 : 1;
-  // tile: up to 256 dense voxels at stride 1, 64 at stride 2 (the halo grows 8x)
-  const int budget = d->stride == 1 ? 8 : 6;            // log2 voxels
-  int lx = ilog2_ceil(p.Mx); if (lx > 5) lx = 5; if (lx < 4 && budget - lx > ilog2_ceil(p.My) + ilog2_ceil(p.Mz)) {}
-  if (d->stride == 2 && lx > 4) lx = 4;
-  int rem = budget - lx;
-  int ly = ilog2_ceil(p.My); if (ly > (rem + 1) / 2) ly = (rem + 1) / 2;
-  rem -= ly;
-  int lz = ilog2_ceil(p.Mz); if (lz > rem) lz = rem;
-  rem -= lz;
-  // leftover budget (small grids): keep the tile at least 16 voxels
-  while (lx + ly + lz < 4) ++lx;
-  p.lx = lx; p.ly = ly; p.lz = lz;
-  pl.TM = 1 << (lx + ly + lz);
-  p.hz = ((1 << lz) - 1) * p.stride + p.k; p.hy = ((1 << ly) - 1) * p.stride + p.k; p.hx = ((1 << lx) - 1) * p.stride + p.k;
-  p.ntx = (p.Mx + (1 << lx) - 1) >> lx; p.nty = (p.My + (1 << ly) - 1) >> ly; p.ntz = (p.Mz + (1 << lz) - 1) >> lz;
-  p.tiles_total = p.ntx * p.nty * ((p.ntz + 7) / 8) * 8;   // ids incl. z padding (tile_coords)
+  // tile: up to 256 dense voxels at stride 1, 64 at stride 2 (the halo grows 8x); shrink until the LDS image
+  // and the per-thread register staging budget (20 x 16-byte pieces) fit
   const int cdb = 32 * (d->form == 0 ? pl.tn : pl.tc), cgb = 32 * (d->form == 0 ? pl.tc : pl.tn);
-  pl.lds = (size_t)pl.TM * cdb * 2 + (size_t)p.hz * p.hy * p.hx * cgb * 2;
-  if (pl.lds > 160 * 1024) return pl;
+  bool fits = false;
+  for (int budget = d->stride == 1 ? 8 : 6; budget >= 4 && !fits; --budget) {
+    int lx = ilog2_ceil(p.Mx); if (lx > 5) lx = 5;
+    if (d->stride == 2 && lx > 4) lx = 4;
+    if (lx > budget) lx = budget;
+    int rem = budget - lx;
+    int ly = ilog2_ceil(p.My); if (ly > (rem + 1) / 2) ly = (rem + 1) / 2;
+    rem -= ly;
+    int lz = ilog2_ceil(p.Mz); if (lz > rem) lz = rem;
+    while (lx + ly + lz < 4) ++lx;     // at least one 16-voxel K step
+    p.lx = lx; p.ly = ly; p.lz = lz;
+    pl.TM = 1 << (lx + ly + lz);
+    p.hz = ((1 << lz) - 1) * p.stride + p.k; p.hy = ((1 << ly) - 1) * p.stride + p.k; p.hx = ((1 << lx) - 1) * p.stride + p.k;
+    pl.lds = (size_t)pl.TM * cdb * 2 + (size_t)p.hz * p.hy * p.hx * cgb * 2;
+    fits = pl.lds <= 160 * 1024 && pl.TM * (cdb / 8) + p.hz * p.hy * p.hx * (cgb / 8) <= 256 * 20;
+  }
+  if (!fits) return pl;
+  p.ntx = (p.Mx + (1 << p.lx) - 1) >> p.lx; p.nty = (p.My + (1 << p.ly) - 1) >> p.ly; p.ntz = (p.Mz + (1 << p.lz) - 1) >> p.lz;
+  p.tiles_total = p.ntx * p.nty * ((p.ntz + 7) / 8) * 8;   // ids incl. z padding (tile_coords)
   p.m_hx = (unsigned)((1ull << 32) / (unsigned)p.hx) + 1u;
   p.m_hxy = (unsigned)((1ull << 32) / (unsigned)(p.hx * p.hy)) + 1u;
   p.cblocks = (p.C + 32 * pl.tc - 1) / (32 * pl.tc);
   const int pairs = ((p.N + 32 * pl.tn - 1) / (32 * pl.tn)) * p.cblocks;
-  // aim for ~1024 blocks in total
-  int chunks = 1024 / (pairs * x->B);
+  // one block per CU: aim for ~512 blocks, but never split the voxels further than needed to fill the chip --
+  // every extra chunk costs a full 27 x n x c fp32 atomic merge (~1.3 TB/s chip-wide)
+  int chunks = 512 / (pairs * x->B);
   if (chunks < 1) chunks = 1;
   if (chunks > p.tiles_total) chunks = p.tiles_total;
   p.tiles_per_block = (p.tiles_total + chunks - 1) / chunks;
@@ -1359,11 +1379,18 @@ int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_te
   pl.p.dwk = dwk;
   const long wsz = (long)d->ksize * d->ksize * d->ksize * dy->C * x->C * (d->per_sample_w ? x->B : 1);
   if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  const bool vecall = pl.p.vec_n && pl.p.vec_c && dy->C % 8 == 0 && x->C % 8 == 0;
 #define WL(TNV, TCV, F)                                                                                          \
   do {                                                                                                           \
-    hipFuncSetAttribute((const void*)conv_mfma_wgrad_k<TNV, TCV, F>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        160 * 1024);                                                                             \
-    hipLaunchKernelGGL((conv_mfma_wgrad_k<TNV, TCV, F>), pl.grid, dim3(256), pl.lds, s, pl.p);                   \
+    if (vecall) {                                                                                                \
+      (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad_k<TNV, TCV, F, 1>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+      hipLaunchKernelGGL((conv_mfma_wgrad_k<TNV, TCV, F, 1>), pl.grid, dim3(256), pl.lds, s, pl.p);              \
+    } else {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad_k<TNV, TCV, F, 0>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+      hipLaunchKernelGGL((conv_mfma_wgrad_k<TNV, TCV, F, 0>), pl.grid, dim3(256), pl.lds, s, pl.p);              \
+    }                                                                                                            \
   } while (0)
   if (d->form == 0) {
     if (pl.tn == 2) WL(2, 1, 0); else if (pl.tc == 2) WL(1, 2, 0); else WL(1, 1, 0);

@@ -42,7 +42,7 @@ def main():
     wk_f, wk_d = ops.PrepWeights.apply(master, r, a.transposed, wd(a_f), wd(a_d))
     y = ops.Conv.apply(x, wk_f, wk_d, None, a.k, a.stride, a.transposed, a.per_sample, 0, None)
     gy = torch.randn_like(y)
-    flops = ops.conv_flops(x.shape, y.shape, a.k, a.stride)
+    flops, _bytes = ops.conv_flops(x.shape, y.shape, a.k, a.stride)
 
     def run_fwd():
         return ops.Conv.apply(x.detach(), wk_f.detach(), wk_d, None, a.k, a.stride, a.transposed, a.per_sample, 0, None)
@@ -63,9 +63,9 @@ def main():
         else:
             run_bwd(a.what)
     torch.cuda.synchronize()
-    for (kind, algo), (n, ms, fl) in sorted(ops.KernelTimer.summary().items()):
-        print(f"{kind}/{algo}: {n} launches, avg {ms / n * 1e3:.1f} us, {fl / (ms * 1e-3) / 1e12:.1f} TFLOP/s "
-              f"({flops / 1e9:.1f} GFLOP per launch)")
+    for (kind, algo), (n, ms, fl, by) in sorted(ops.KernelTimer.summary().items()):
+        print(f"{kind}/{algo}: {n} launches, avg {ms / n * 1e3:.1f} us, {fl / (ms * 1e-3) / 1e12:.1f} TFLOP/s, "
+              f"{by / (ms * 1e-3) / 1e9:.0f} GB/s algorithmic ({flops / 1e9:.1f} GFLOP per launch)")
 
 
 if __name__ == "__main__":
