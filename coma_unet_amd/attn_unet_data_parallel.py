@@ -53,10 +53,6 @@ class UpBlock(nn.Module):
         return self.up(x, covariate, out)
 
 
-class _ConvOnly(nn.Sequential):
-    """Sequential(Convolution(conv_only), BatchNorm3d[, Sigmoid]) parameter layout of MONAI AttentionBlock."""
-
-
 class ObservableAttentionBlock(nn.Module):
     """MONAI AttentionBlock + attn_unet_data_parallel.py:134-150: the attention gate
     psi = sigmoid(BN(W_psi relu(BN(W_g g) + BN(W_x x)))),  out = x * psi."""

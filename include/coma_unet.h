@@ -71,7 +71,8 @@ typedef struct coma_conv_desc {
   int32_t pad;            /* 0 or 1 */
   int32_t form;           /* 0 conv, 1 tconv */
   int32_t per_sample_w;   /* 1: wk/bias have a leading B dim (CondConv) */
-  int32_t algo;           /* 0 auto, 1 direct (VALU fp32), 2 MFMA bf16 implicit GEMM */
+  int32_t algo;           /* 0 auto, 1 force the direct VALU fp32 kernels, 2 MFMA wherever the shape allows
+                             (bf16 tensors only; unsupported shapes still take the direct kernels) */
 } coma_conv_desc;
 
 int         coma_abi_version(void);
@@ -85,7 +86,7 @@ const char* coma_last_error(void);
 int coma_weight_prep(const float* master, const float* r, int32_t E, int32_t Bw,
                      int32_t N, int32_t C, int32_t taps, int64_t se, int64_t sn, int64_t sc,
                      void* out, int32_t out_dtype, void* stream);
-/* dwk: fp32 [Bw][taps][N][C]  ->  dmaster (+=, fp32, master layout), dr [Bw][E] (=, fp32) */
+/* dwk: fp32 [Bw][taps][N][C]  ->  dmaster (=, fp32, master layout), dr [Bw][E] (=, fp32) */
 int coma_weight_prep_bwd(const float* dwk, const float* master, const float* r, int32_t E,
                          int32_t Bw, int32_t N, int32_t C, int32_t taps, int64_t se,
                          int64_t sn, int64_t sc, float* dmaster, float* dr, void* stream);

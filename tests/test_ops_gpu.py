@@ -1,8 +1,6 @@
 """Per-kernel parity: every C-ABI entry point against a CPU fp64 torch restatement of the
 same reference op (the ATen/MONAI op it replaces), on seeded inputs.  Tolerances: fp32 path
 1e-5 rel-L2 (summation-order differences only), bf16 path 2e-2 (bf16 storage rounding)."""
-import itertools
-
 import pytest
 import torch
 import torch.nn.functional as F
