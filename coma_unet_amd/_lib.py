@@ -62,6 +62,7 @@ SIGNATURES = {
     "coma_roi_mse_bwd": (_i32, [_TP, _TP, _vp, _vp, _TP, _vp]),
     "coma_l1_fwd": (_i32, [_TP, _TP, _vp, _vp, _sz, _vp]),
     "coma_l1_bwd": (_i32, [_TP, _TP, _vp, _TP, _vp]),
+    "coma_eval_stats": (_i32, [_TP, _TP, _TP, _vp, _i32, _vp, _vp]),
     "coma_adamw": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
 }
 

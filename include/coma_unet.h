@@ -171,6 +171,13 @@ int coma_l1_fwd(const coma_tensor* pred, const coma_tensor* gt, float* loss, voi
 int coma_l1_bwd(const coma_tensor* pred, const coma_tensor* gt, const float* gout,
                 const coma_tensor* dpred, void* stream);
 
+/* ---- evaluation statistics: one pass over (pred, gt, roi) giving, per sample and per
+ *      bin (n_roi ROIs + the whole volume), the sums behind calc_roi_metrics (attn_unet_data_parallel.py:1361-1397),
+ *      the global MAE/MAPE/RSE/RRMSE of contrastive_test (:1214-1231) and RoiCorrMetric (:49-60).
+ *      stats: fp64 [B][n_roi+1][8] = {count, sum|d|, sum d^2, sum g, sum g^2, sum p, sum|d/g| (non-NaN), #non-NaN} ---- */
+int coma_eval_stats(const coma_tensor* pred, const coma_tensor* gt, const coma_tensor* roi,
+                    const int32_t* roi_ids, int32_t n_roi, double* stats, void* stream);
+
 /* ---- AdamW over a flat fp32 buffer (torch.optim.AdamW defaults,
  *      attn_unet_data_parallel.py:736): p,g,m,v length n; step counted from 1.  When step_dev is
  *      non-NULL the step count is read from that device int32 instead (hipGraph replay). ---- */

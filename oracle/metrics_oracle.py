@@ -1,0 +1,78 @@
+"""CPU ORACLE (test infrastructure, NOT product code) -- evaluation metrics.
+
+Literal CPU restatement of /root/reference/attn_unet_data_parallel.py:
+  calc_roi_metrics ............ :1361-1397  (only change: masks are created on `roi.device`;
+                                             upstream passes roi.get_device() which is -1 on CPU)
+  per-batch global metrics .... :1214-1231  (MAE, nan-aware MAPE, RSE, RRMSE)
+  RoiCorrMetric.acc_roi_corr .. :49-60
+**parity unpinned**: the reference ships no fixtures for these and its module cannot be imported (MONAI);
+pinned by source text only.  Imported by tests/ only.
+"""
+import numpy as np
+import torch
+
+
+def calc_roi_metrics(roi_indices, roi_weights, roi_maes, roi_mapes, roi_rses, roi_wrrmses, roi_nonnan_voxels,
+                     tau_volume, roi, pred, diff, raw_mape):
+    dev = roi.device
+    roi_mask = torch.zeros(roi.size(), device=dev, dtype=pred.dtype)
+    roi_bool_mask = torch.zeros(roi.size(), device=dev, dtype=torch.bool)
+    temp_roi_maes = torch.zeros(len(roi_indices), device=dev, dtype=pred.dtype)
+    temp_roi_mapes = torch.zeros(len(roi_indices), device=dev, dtype=pred.dtype)
+    temp_roi_rses = torch.zeros(len(roi_indices), device=dev, dtype=pred.dtype)
+    temp_roi_wrrmses = torch.zeros(len(roi_indices), device=dev, dtype=pred.dtype)
+    temp_roi_nonnan_voxels = torch.zeros(len(roi_indices), device=dev, dtype=pred.dtype)
+    for i, idx in enumerate(roi_indices):
+        roi_mask[:] = 0
+        roi_bool_mask[:] = False
+        roi_mask[roi == idx] = 1
+        roi_bool_mask[roi == idx] = True
+        roi_mask_size = torch.count_nonzero(roi_mask, dim=(-3, -2, -1))
+        nr_roi_mae = torch.sum(torch.abs(diff) * roi_mask, dim=(-3, -2, -1)) / roi_mask_size
+        temp_roi_maes[i] += torch.sum(nr_roi_mae)
+        roi_raw_mape = raw_mape[roi_bool_mask]
+        temp_roi_mapes[i] = torch.nansum(roi_raw_mape)
+        temp_roi_nonnan_voxels[i] = (torch.count_nonzero(roi_bool_mask) - torch.count_nonzero(torch.isnan(roi_raw_mape))).item()
+        num = torch.sum(roi_mask * torch.square(diff), dim=(-3, -2, -1))
+        den = torch.sum(roi_mask * torch.square(tau_volume), dim=(-3, -2, -1))
+        temp_roi_wrrmses[i] = torch.sum(torch.sqrt(num / den))
+        gt_mean = torch.sum(roi_mask * tau_volume, dim=(-3, -2, -1)) / roi_mask_size
+        roi_se_num = torch.sum(roi_mask * torch.square(tau_volume - pred), dim=(-3, -2, -1))
+        roi_se_den = torch.sum(roi_mask * torch.square(tau_volume - gt_mean.view(-1, 1, 1, 1, 1)), dim=(-3, -2, -1))
+        temp_roi_rses[i] += torch.sum(roi_se_num / roi_se_den)
+    return temp_roi_maes, temp_roi_mapes, temp_roi_rses, temp_roi_wrrmses, temp_roi_nonnan_voxels
+
+
+def batch_global_metrics(pred, tau_volume):
+    """The per-batch terms contrastive_test accumulates (:1214-1231)."""
+    diff = pred - tau_volume
+    mae = torch.mean(torch.abs(diff))
+    nr_mape = torch.where(torch.abs(tau_volume) > 1e-08, torch.abs((tau_volume - pred) / tau_volume),
+                          torch.full_like(pred, float("nan")))
+    mape_sum = torch.nansum(nr_mape * 100, dim=(-3, -2, -1)).sum()
+    mape_count = nr_mape.numel() - int(torch.isnan(nr_mape).sum())
+    gt_mean = torch.mean(tau_volume, dim=(-3, -2, -1))
+    num = torch.sum(torch.square(tau_volume - pred), dim=(-3, -2, -1))
+    den = torch.sum(torch.square(tau_volume - gt_mean.view(-1, 1, 1, 1, 1)), dim=(-3, -2, -1))
+    rse = torch.mean(num / den)
+    rrmse = torch.nanmean(torch.sqrt(num / torch.sum(torch.square(tau_volume), dim=(-3, -2, -1))))
+    return dict(mae=mae, mape_sum=mape_sum, mape_count=mape_count, rse=rse, rrmse=rrmse)
+
+
+class RoiCorrMetric:   # :36-96 (accumulation + correlation only; CSV dumps are out of scope)
+    def __init__(self, roi_indices):
+        self.roi_indices = roi_indices
+        self.pred_means = [[] for _ in roi_indices]
+        self.gt_means = [[] for _ in roi_indices]
+
+    def acc_roi_corr(self, pred, gt, roi):
+        roi_mask = torch.zeros(roi.size(), device=roi.device, dtype=pred.dtype)
+        for i, idx in enumerate(self.roi_indices):
+            roi_mask[:] = 0
+            roi_mask[roi == idx] = 1
+            cnt = torch.count_nonzero(roi_mask, dim=(-3, -2, -1))
+            self.pred_means[i].extend((torch.sum(roi_mask * pred, dim=(-3, -2, -1)) / cnt).detach().cpu().numpy().flatten())
+            self.gt_means[i].extend((torch.sum(roi_mask * gt, dim=(-3, -2, -1)) / cnt).detach().cpu().numpy().flatten())
+
+    def calc_roi_corr(self):
+        return np.array([np.corrcoef(self.pred_means[i], self.gt_means[i])[0, 1] for i in range(len(self.roi_indices))])
