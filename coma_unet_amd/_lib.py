@@ -38,6 +38,8 @@ SIGNATURES = {
     "coma_last_error": (C.c_char_p, []),
     "coma_weight_prep": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
     "coma_weight_prep_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "coma_routing_fwd": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "coma_routing_bwd": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "coma_conv_pick_algo": (_i32, [_DP, _TP, _TP]),
     "coma_conv_fwd": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _vp]),
     "coma_conv_fwd_norm_stats": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _i32, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),

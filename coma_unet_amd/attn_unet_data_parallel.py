@@ -236,6 +236,7 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         self.volume_shape = vs
         # the duplicated pass of :664/:666 covers the U-Net only; the heads run once per forward
         cfg1 = Config(cfg.compute_dtype, cfg.conv_algo, 1)
+        self.cfg_heads = cfg1
         self.projection_heads = nn.ModuleList(
             [ProjectionHead(cfg1, channels[i], int((128 / (2 ** i)) ** 3), latent_spaces[i]) for i in range(len(channels))])
         self.final_projection_head = nn.Sequential(nn.AdaptiveAvgPool3d(1), nn.Linear(out_channels, latent_spaces[-1]), nn.ReLU())
@@ -303,9 +304,19 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         return final, enc, dec
 
     def forward(self, x, covariate=None, roi_pred_dicts=None, sample_roi_mask=None):
-        if covariate is not None and x.device != covariate.device:
-            covariate = covariate.to(device=x.device)
+        if covariate is not None:     # one cast for every conditional layer (each routing reads fp32 covariates)
+            covariate = covariate.to(device=x.device, dtype=torch.float32).contiguous()
         xi = to_internal(x).to(self.cfg.compute_dtype)
+        cfgs = (self.cfg, self.cfg_heads) if self.training else ()
+        for c in cfgs:
+            c.begin_forward()
+        try:
+            return self._forward(x, xi, covariate, roi_pred_dicts, sample_roi_mask)
+        finally:
+            for c in cfgs:
+                c.end_forward()
+
+    def _forward(self, x, xi, covariate, roi_pred_dicts, sample_roi_mask):
         # which learned prompts this batch selects (:638-639).  The reference does one .item() per sample
         # mid-forward; here it is one host read BEFORE any kernel is queued, and `static_prompts` skips it
         # (both prompts then always receive a gradient, zeros when unselected).

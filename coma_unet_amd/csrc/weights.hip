@@ -121,3 +121,94 @@ extern "C" int coma_weight_prep_bwd(const float* dwk, const float* master, const
   COMA_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// CondConv routing: r = sigmoid(cov . Wr^T + br), bias_mix = r . bias_e   
+// A few hundred numbers per layer: one launch forward, one backward, instead of the ~15 tiny
+// GEMM / elementwise launches the same algebra costs through a tensor library.
+// ---------------------------------------------------------------------------------------
+#define ROUTE_MAX_BE 64
+
+__global__ void __launch_bounds__(256) routing_fwd_k(const float* __restrict__ cov, int B, int NC, const float* __restrict__ Wr,
+                                                     const float* __restrict__ br, int E, const float* __restrict__ bias_e, int N,
+                                                     float* __restrict__ r_out, float* __restrict__ bias_mix) {
+  __shared__ float r[ROUTE_MAX_BE];
+  if (threadIdx.x < B * E) {
+    const int b = threadIdx.x / E, e = threadIdx.x % E;
+    float z = br[e];
+    for (int c = 0; c < NC; ++c) z = fmaf(cov[b * NC + c], Wr[e * NC + c], z);
+    const float v = 1.f / (1.f + expf(-z));
+    r[threadIdx.x] = v;
+    if (blockIdx.x == 0) r_out[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (!bias_mix) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B * N) {
+    const int b = i / N, n = i % N;
+    float a = 0.f;
+    for (int e = 0; e < E; ++e) a = fmaf(r[b * E + e], bias_e[e * N + n], a);
+    bias_mix[i] = a;
+  }
+}
+
+__global__ void __launch_bounds__(256) routing_bwd_k(const float* __restrict__ cov, int B, int NC, const float* __restrict__ r, int E,
+                                                     const float* __restrict__ bias_e, int N, const float* __restrict__ dr_w,
+                                                     const float* __restrict__ dbias_mix, float* __restrict__ dWr,
+                                                     float* __restrict__ dbr, float* __restrict__ dbias_e) {
+  __shared__ float dz[ROUTE_MAX_BE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int p = wave; p < B * E; p += 4) {          // dr = dr_w + dbias_mix . bias_e^T, one wave per (b, e)
+    const int b = p / E, e = p % E;
+    float a = 0.f;
+    if (dbias_mix)
+      for (int n = lane; n < N; n += 64) a = fmaf(dbias_mix[b * N + n], bias_e[e * N + n], a);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) {
+      const float rv = r[p];
+      dz[p] = (a + (dr_w ? dr_w[p] : 0.f)) * rv * (1.f - rv);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < E * NC; i += 256) {
+    const int e = i / NC, c = i % NC;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a = fmaf(dz[b * E + e], cov[b * NC + c], a);
+    dWr[i] = a;
+  }
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dz[b * E + e];
+    dbr[e] = a;
+  }
+  if (dbias_e)
+    for (int i = threadIdx.x; i < E * N; i += 256) {
+      const int e = i / N, n = i % N;
+      float a = 0.f;
+      if (dbias_mix)
+        for (int b = 0; b < B; ++b) a = fmaf(r[b * E + e], dbias_mix[b * N + n], a);
+      dbias_e[i] = a;
+    }
+}
+
+extern "C" int coma_routing_fwd(const float* cov, int32_t B, int32_t NC, const float* Wr, const float* br, int32_t E,
+                                const float* bias_e, int32_t N, float* r, float* bias_mix, void* stream) {
+  COMA_CHECK(cov && Wr && br && r, "routing_fwd: null argument");
+  COMA_CHECK(B >= 1 && E >= 1 && B * E <= ROUTE_MAX_BE && NC >= 1, "routing_fwd: B*E=%d out of range", B * E);
+  COMA_CHECK(!bias_mix || (bias_e && N >= 1), "routing_fwd: bias_mix without expert biases");
+  const int blocks = bias_mix ? (B * N + 255) / 256 : 1;
+  hipLaunchKernelGGL(routing_fwd_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cov, B, NC, Wr, br, E, bias_e, N, r, bias_mix);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coma_routing_bwd(const float* cov, int32_t B, int32_t NC, const float* r, int32_t E, const float* bias_e, int32_t N,
+                                const float* dr_w, const float* dbias_mix, float* dWr, float* dbr, float* dbias_e, void* stream) {
+  COMA_CHECK(cov && r && dWr && dbr, "routing_bwd: null argument");
+  COMA_CHECK(B >= 1 && E >= 1 && B * E <= ROUTE_MAX_BE && NC >= 1, "routing_bwd: B*E=%d out of range", B * E);
+  COMA_CHECK(!(dbias_mix || dbias_e) || (bias_e && N >= 1), "routing_bwd: bias gradient without expert biases");
+  hipLaunchKernelGGL(routing_bwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, cov, B, NC, r, E, bias_e, N, dr_w, dbias_mix, dWr,
+                     dbr, dbias_e);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}

@@ -35,6 +35,8 @@ class GradReducer:
         self.group = group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = overlap
+        if overlap and hasattr(optimizer, "set_write_through"):
+            optimizer.set_write_through(False)     # hook-driven overlap needs autograd's AccumulateGrad to run
         self._hooks = []
         self._works = []
         self._buckets = None      # list of [start, end, n_params_pending, n_params_total]

@@ -25,6 +25,15 @@ class Config:
         self.compute_dtype = compute_dtype
         self.conv_algo = conv_algo            # 0 auto, 1 direct VALU fp32, 2 MFMA bf16
         self.bn_updates_per_forward = bn_updates_per_forward
+        self.nbt_pending = None               # list while a model forward collects BatchNorm step counters
+
+    def begin_forward(self):
+        self.nbt_pending = []
+
+    def end_forward(self):
+        if self.nbt_pending:
+            torch._foreach_add_(self.nbt_pending, self.bn_updates_per_forward)
+        self.nbt_pending = None
 
 
 def _wdtype(algo):
@@ -69,7 +78,10 @@ def _norm_params(cfg, bn, training):
         k = cfg.bn_updates_per_forward
         momentum = 1.0 - (1.0 - bn.momentum) ** k     # k identical updates folded into one
         if training:
-            bn.num_batches_tracked += k
+            if cfg.nbt_pending is not None:       # the model adds all counters in one multi-tensor launch
+                cfg.nbt_pending.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked += k
     return gamma, beta, rmean, rvar, momentum, eps
 
 
@@ -162,11 +174,11 @@ class CondConv3d(nn.Module):
 
 def conv_cond(cfg, x, cc: CondConv3d, covariate, out=None, norm=None):
     B = x.shape[0]
-    cov = covariate.reshape(B, -1).to(device=x.device, dtype=torch.float32)
+    cov = covariate.reshape(B, -1)
+    if cov.dtype != torch.float32 or cov.device != x.device or not cov.is_contiguous():
+        cov = cov.to(device=x.device, dtype=torch.float32).contiguous()   # the model casts once per forward
     assert cov.shape[1] == cc.num_covars, (cov.shape, cc.num_covars)
-    # routing: a (B x num_covars) @ (num_covars x E) product + sigmoid -- host-side glue on <= 64 numbers
-    r = torch.sigmoid(F.linear(cov, cc.routing.weight, cc.routing.bias))
-    bias = r @ cc.bias                                         # (B, Cout), same glue
+    r, bias = ops.Routing.apply(cov, cc.routing.weight, cc.routing.bias, cc.bias)    # (B, E), (B, Cout)
     a_f, a_d = ops.pick_algo(x.shape, x.dtype, cc.out_channels, cc.kernel_size, cc.stride, cc.is_transposed, True,
                              x.device, cfg.conv_algo)
     need_dx = x.requires_grad

@@ -29,14 +29,14 @@ class KernelTimer:
     records = []   # (kind, algo, flops, ev_start, ev_end)
 
     @classmethod
-    def run(cls, kind, algo, flops, fn):
+    def run(cls, kind, algo, flops, fn, tag=None):
         if not cls.enabled:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = fn()
         e1.record()
-        cls.records.append((kind, algo, flops, e0, e1))
+        cls.records.append((kind, algo, flops, e0, e1, tag))
         return r
 
     @classmethod
@@ -44,10 +44,20 @@ class KernelTimer:
         """{(kind, algo): (launches, total_ms, total_flops, total_bytes)} -- call after torch.cuda.synchronize().
         `flops` entries are (flops, algorithmic_bytes) pairs."""
         out = {}
-        for kind, algo, fb, e0, e1 in cls.records:
+        for kind, algo, fb, e0, e1, _tag in cls.records:
             fl, by = fb if isinstance(fb, tuple) else (fb, 0.0)
             n, ms, f0, b0 = out.get((kind, algo), (0, 0.0, 0.0, 0.0))
             out[(kind, algo)] = (n + 1, ms + e0.elapsed_time(e1), f0 + fl, b0 + by)
+        return out
+
+    @classmethod
+    def by_layer(cls):
+        """{(kind, tag): (launches, total_ms, total_flops)} for the per-layer table (profiles/layer_table.py)."""
+        out = {}
+        for kind, algo, fb, e0, e1, tag in cls.records:
+            fl = fb[0] if isinstance(fb, tuple) else fb
+            n, ms, f0 = out.get((kind, tag), (0, 0.0, 0.0))
+            out[(kind, tag)] = (n + 1, ms + e0.elapsed_time(e1), f0 + fl)
         return out
 
 
@@ -75,6 +85,26 @@ def _f32(n, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+class GradSink:
+    """Write-through parameter gradients.  ``FusedAdamW(write_through=True)`` marks every parameter whose
+    ``.grad`` is a slot of its flat gradient buffer; the backward kernels then write that slot directly ("=")
+    and hand autograd ``None`` -- no temporary, no AccumulateGrad add launch per parameter.  A second use of the
+    same parameter inside one step falls back to the ordinary returned gradient (autograd adds it to the slot).
+    Post-accumulate-grad hooks do not fire for sunk gradients, so hook-driven overlap keeps this off."""
+    written = set()
+
+    @classmethod
+    def begin_step(cls):
+        cls.written.clear()
+
+    @classmethod
+    def slot(cls, p):
+        if p is None or not getattr(p, "_coma_sink", False) or p.grad is None or id(p) in cls.written:
+            return None
+        cls.written.add(id(p))
+        return p.grad
+
+
 # --------------------------------------------------------------------------------------
 # weights: CondConv expert mixing + kernel-layout cast
 # --------------------------------------------------------------------------------------
@@ -87,6 +117,8 @@ class PrepWeights(Function):
 
     @staticmethod
     def forward(ctx, master, r, transposed, fwd_dtype, dgrad_dtype):
+        ctx.set_materialize_grads(False)
+        ctx.p_master = master
         has_e = r is not None
         m = master if has_e else master.unsqueeze(0)
         assert m.is_contiguous() and m.dtype == torch.float32
@@ -116,14 +148,53 @@ class PrepWeights(Function):
 
     @staticmethod
     def backward(ctx, dwk_f, _dwk_d):
+        if dwk_f is None:
+            return None, None, None, None, None
         master, rr = ctx.saved_tensors
         has_e, E, Bw, cout, cin, taps, se, sn_f, sc_f = ctx.meta
         dwk = dwk_f.contiguous().float()
-        dmaster = torch.empty_like(master)
+        sink = GradSink.slot(ctx.p_master)
+        dmaster = sink if sink is not None else torch.empty_like(master)
         dr = _f32((Bw, E), master.device) if has_e else None
         check(lib.coma_weight_prep_bwd(ptr(dwk), ptr(master), ptr(rr), E, Bw, cout, cin, taps, se, sn_f, sc_f,
                                        ptr(dmaster), ptr(dr), L.stream()), "coma_weight_prep_bwd")
-        return dmaster, dr, None, None, None
+        return (None if sink is not None else dmaster), dr, None, None, None
+
+
+class Routing(Function):
+    """CondConv routing + per-sample bias mix in one launch each way:
+    r = sigmoid(cov @ Wr^T + br) (B, E);  bias_mix = r @ bias_e (B, Cout)."""
+
+    @staticmethod
+    def forward(ctx, cov, Wr, br, bias_e):
+        ctx.set_materialize_grads(False)
+        assert cov.dtype == torch.float32 and cov.is_contiguous() and cov.is_cuda
+        B, NC = cov.shape
+        E, N = Wr.shape[0], bias_e.shape[1]
+        r, bm = _f32((B, E), cov.device), _f32((B, N), cov.device)
+        check(lib.coma_routing_fwd(ptr(cov), B, NC, ptr(Wr), ptr(br), E, ptr(bias_e), N, ptr(r), ptr(bm), L.stream()),
+              "coma_routing_fwd")
+        ctx.save_for_backward(cov, r, bias_e)
+        ctx.params = (Wr, br, bias_e)
+        return r, bm
+
+    @staticmethod
+    def backward(ctx, dr, dbm):
+        cov, r, bias_e = ctx.saved_tensors
+        Wr, br, be = ctx.params
+        B, NC = cov.shape
+        E, N = r.shape[1], bias_e.shape[1]
+        dev = cov.device
+        sinks = [GradSink.slot(p) for p in (Wr, br, be)]
+        dWr = sinks[0] if sinks[0] is not None else _f32((E, NC), dev)
+        dbr = sinks[1] if sinks[1] is not None else _f32((E,), dev)
+        dbe = sinks[2] if sinks[2] is not None else _f32((E, N), dev)
+        dr = dr.contiguous() if dr is not None else None
+        dbm = dbm.contiguous() if dbm is not None else None
+        check(lib.coma_routing_bwd(ptr(cov), B, NC, ptr(r), E, ptr(bias_e), N, ptr(dr), ptr(dbm), ptr(dWr), ptr(dbr), ptr(dbe),
+                                   L.stream()), "coma_routing_bwd")
+        return (None, None if sinks[0] is not None else dWr, None if sinks[1] is not None else dbr,
+                None if sinks[2] is not None else dbe)
 
 
 # --------------------------------------------------------------------------------------
@@ -160,6 +231,8 @@ class Conv(Function):
 
     @staticmethod
     def forward(ctx, x, wk_f, wk_d, bias, ksize, stride, transposed, per_sample, algo, out, norm=None):
+        ctx.set_materialize_grads(False)
+        ctx.p_bias = bias if not per_sample else None
         B, Do, Ho, Wo = conv_out_grid(x.shape, ksize, stride, transposed)
         n = wk_f.shape[2]
         y = out.t if out is not None else _new((B, Do, Ho, Wo, n), x.dtype, x.device)
@@ -172,7 +245,8 @@ class Conv(Function):
         if norm is None:
             KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
                             lambda: check(lib.coma_conv_fwd(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), ct(y),
-                                                            L.stream()), "coma_conv_fwd"))
+                                                            L.stream()), "coma_conv_fwd"),
+                            tag=(tuple(x.shape), n, ksize, stride, form))
             return y
         mode, eps, rmean, rvar, momentum = norm
         G = B if mode == L.NORM_INSTANCE else 1
@@ -183,7 +257,8 @@ class Conv(Function):
                         lambda: check(lib.coma_conv_fwd_norm_stats(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), cy,
                                                                    mode, eps, ptr(mean), ptr(rstd), ptr(rmean), ptr(rvar),
                                                                    momentum, ptr(ws), ws.numel(), L.stream()),
-                                      "coma_conv_fwd_norm_stats"))
+                                      "coma_conv_fwd_norm_stats"),
+                        tag=(tuple(x.shape), n, ksize, stride, form))
         ctx.mark_non_differentiable(mean, rstd)
         return y, mean, rstd
 
@@ -192,6 +267,9 @@ class Conv(Function):
         x, wk_d = ctx.saved_tensors
         ksize, stride, form, per_sample, algo, has_bias, wshape = ctx.meta
         dx = dwk = dbias = None
+        if dy is None:
+            return (None,) * 11
+        bias_sunk = False
         s = L.stream()
         if ctx.needs_input_grad[0]:
             assert wk_d is not None, "data gradient requested but dgrad weights were not prepared"
@@ -200,7 +278,8 @@ class Conv(Function):
                             conv_flops(dy.shape, dx.shape, ksize, stride),
                             lambda: check(lib.coma_conv_fwd(_desc(ksize, stride, 1 - form, per_sample, algo), ct(dy),
                                                             ptr(wk_d), L.dtype_code(wk_d.dtype), None, ct(dx), s),
-                                          "coma_conv_fwd(dgrad)"))
+                                          "coma_conv_fwd(dgrad)"),
+                            tag=(tuple(x.shape), dy.shape[4], ksize, stride, form))
         if ctx.needs_input_grad[1]:
             d = _desc(ksize, stride, form, per_sample, algo)
             cx, cdy = ct(x), ct(dy)
@@ -208,12 +287,15 @@ class Conv(Function):
             ws = workspace(nb, x.device)
             dwk = _f32(wshape, x.device)
             if has_bias:
-                dbias = _f32((x.shape[0], wshape[2]) if per_sample else (wshape[2],), x.device)
+                sink = GradSink.slot(ctx.p_bias)
+                bias_sunk = sink is not None
+                dbias = sink if bias_sunk else _f32((x.shape[0], wshape[2]) if per_sample else (wshape[2],), x.device)
             walgo = conv_class("mfma" if lib.coma_conv_wgrad_algo(d, cx, cdy) == 2 else "direct", x.shape[4], dy.shape[4])
             KernelTimer.run("conv_wgrad", walgo, conv_flops(x.shape, dy.shape, ksize, stride),
                             lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias), ptr(ws), ws.numel(), s),
-                                          "coma_conv_wgrad"))
-        return dx, dwk, None, dbias, None, None, None, None, None, None, None
+                                          "coma_conv_wgrad"),
+                            tag=(tuple(x.shape), dy.shape[4], ksize, stride, form))
+        return dx, dwk, None, (None if bias_sunk else dbias), None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -222,6 +304,7 @@ class Conv(Function):
 class NormAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, slope, rmean, rvar, mode, act, momentum, eps, training, out, pre=None):
+        ctx.params = (gamma, beta, slope)
         dev = x.device
         B, C = x.shape[0], x.shape[4]
         G = B if mode == L.NORM_INSTANCE else 1
@@ -255,15 +338,17 @@ class NormAct(Function):
         dev = x.device
         C = x.shape[4]
         dx = _new(x.shape, x.dtype, dev)
-        dgamma = _f32(C, dev) if gamma is not None else None
-        dbeta = _f32(C, dev) if beta is not None else None
-        dslope = _f32(1, dev) if slope is not None else None
+        sinks = [GradSink.slot(p) for p in ctx.params]
+        dgamma = sinks[0] if sinks[0] is not None else (_f32(C, dev) if gamma is not None else None)
+        dbeta = sinks[1] if sinks[1] is not None else (_f32(C, dev) if beta is not None else None)
+        dslope = sinks[2] if sinks[2] is not None else (_f32(1, dev) if slope is not None else None)
         cx = ct(x)
         ws = workspace(lib.coma_norm_ws_bytes(cx), dev)
         check(lib.coma_norm_act_bwd(cx, ct(dy), mode, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(slope),
                                     ct(dx), ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(ws), ws.numel(), L.stream()),
               "coma_norm_act_bwd")
-        return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None, None
+        return (dx, None if sinks[0] is not None else dgamma, None if sinks[1] is not None else dbeta,
+                None if sinks[2] is not None else dslope, None, None, None, None, None, None, None, None, None)
 
 
 # --------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ from . import ops
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, dynamic=()):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, dynamic=(), write_through=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         assert len(self.param_groups) == 1, "one parameter group (the reference uses one)"
@@ -24,6 +24,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
         self._flat_params = []
         self._flat_step = 0
+        # write_through: backward kernels store parameter gradients straight into the flat buffer's slots
+        # (ops.GradSink) -- no per-parameter AccumulateGrad launch.  Off when a GradReducer drives its
+        # all-reduce from post-accumulate-grad hooks (those do not fire for sunk gradients).
+        self.write_through = write_through
 
     # -- layout -------------------------------------------------------------------------
     def _build(self):
@@ -44,6 +48,7 @@ class FusedAdamW(torch.optim.Optimizer):
             p.data = self.flat_p[off:off + k].view(p.shape)
             p.grad = self.flat_g[off:off + k].view(p.shape)
             self._offsets[id(p)] = (off, k)
+            p._coma_sink = bool(self.write_through)
             off += k
         self._flat_params = ps
         self._flat_ids = {id(p) for p in ps}
@@ -53,7 +58,13 @@ class FusedAdamW(torch.optim.Optimizer):
     def built(self):
         return self.flat_p is not None
 
+    def set_write_through(self, on: bool):
+        self.write_through = bool(on)
+        for p in self._flat_params:
+            p._coma_sink = self.write_through
+
     def zero_grad(self, set_to_none=True):
+        ops.GradSink.begin_step()
         for p in self.param_groups[0]["params"]:
             if self.built and id(p) in self._flat_ids:
                 continue

@@ -11,10 +11,11 @@ from .optim import FusedAdamW
 from .data_parallel import GradReducer
 
 
-def make_optimizer(model, lr=1e-3):
-    """torch.optim.AdamW(model.parameters(), lr) of :736, fused."""
+def make_optimizer(model, lr=1e-3, write_through=True):
+    """torch.optim.AdamW(model.parameters(), lr) of :736, fused.  ``write_through``: parameter gradients are
+    written by the backward kernels straight into the optimizer's flat gradient buffer (see ops.GradSink)."""
     dyn = [model.pos_dynamic_prompt, model.neg_dynamic_prompt] if not getattr(model, "static_prompts", False) else []
-    return FusedAdamW(model.parameters(), lr=lr, dynamic=dyn)
+    return FusedAdamW(model.parameters(), lr=lr, dynamic=dyn, write_through=write_through)
 
 
 def forward_loss(model, criterion, batch):
@@ -60,6 +61,7 @@ class GraphedTrainStep:
         if reducer is not None:
             reducer.overlap = False          # hooks do not fire under replay
             reducer.remove_hooks()
+            optimizer.set_write_through(True)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -91,6 +91,18 @@ int coma_weight_prep_bwd(const float* dwk, const float* master, const float* r, 
                          int32_t Bw, int32_t N, int32_t C, int32_t taps, int64_t se,
                          int64_t sn, int64_t sc, float* dmaster, float* dr, void* stream);
 
+/* ---- CondConv routing (call sites attn_unet_data_parallel.py:285-306):
+ *      r[b][e] = sigmoid(cov[b] . Wr[e] + br[e]);  bias_mix[b][n] = sum_e r[b][e] * bias_e[e][n]
+ * cov fp32 [B][NC], Wr [E][NC], br [E], bias_e [E][N] (or NULL with bias_mix NULL); B*E <= 64.   */
+int coma_routing_fwd(const float* cov, int32_t B, int32_t NC, const float* Wr, const float* br,
+                     int32_t E, const float* bias_e, int32_t N, float* r, float* bias_mix,
+                     void* stream);
+/* dr_w [B][E] (gradient reaching r through the mixed weights, or NULL), dbias_mix [B][N] (or
+ * NULL)  ->  dWr [E][NC], dbr [E], dbias_e [E][N] (or NULL); all written with "=".             */
+int coma_routing_bwd(const float* cov, int32_t B, int32_t NC, const float* r, int32_t E,
+                     const float* bias_e, int32_t N, const float* dr_w, const float* dbias_mix,
+                     float* dWr, float* dbr, float* dbias_e, void* stream);
+
 /* ---- convolution (nn.Conv3d / nn.ConvTranspose3d and their data-gradients) ---- */
 /* which kernel family algo==0 resolves to for this problem: 1 direct (wants fp32 wk),
  * 2 MFMA (wants bf16 wk).  The host prepares the kernel-layout weights accordingly.   */

@@ -389,3 +389,38 @@ def test_conv_mfma_fwd_dgrad_wgrad(case, per_sample):
     if not per_sample:
         gw = gw.sum(0, keepdim=True)
     assert rel(wk_f.grad, gw) < 5e-3
+
+
+@pytest.mark.parametrize("B,NC,E,N", [(1, 5, 8, 32), (2, 6, 8, 512), (4, 5, 8, 1), (8, 6, 8, 64)])
+def test_routing_matches_torch(B, NC, E, N):
+    """CondConv routing: sigmoid(Linear(cov)) and the per-sample bias mix, forward and backward,
+    against the same algebra in stock torch (fp32 both sides; tolerance 1e-5 relative)."""
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(B * 100 + N)
+    cov = torch.rand((B, NC), generator=g).cuda()
+    Wr = (torch.randn((E, NC), generator=g) * 0.5).cuda().requires_grad_(True)
+    br = (torch.randn((E,), generator=g) * 0.5).cuda().requires_grad_(True)
+    be = torch.randn((E, N), generator=g).cuda().requires_grad_(True)
+    gr = torch.randn((B, E), generator=g).cuda()
+    gb = torch.randn((B, N), generator=g).cuda()
+    r, bm = ops.Routing.apply(cov, Wr, br, be)
+    ((r * gr).sum() + (bm * gb).sum()).backward()
+    got = [r.detach(), bm.detach(), Wr.grad.clone(), br.grad.clone(), be.grad.clone()]
+    for p in (Wr, br, be):
+        p.grad = None
+    r2 = torch.sigmoid(torch.nn.functional.linear(cov, Wr, br))
+    bm2 = r2 @ be
+    ((r2 * gr).sum() + (bm2 * gb).sum()).backward()
+    want = [r2.detach(), bm2.detach(), Wr.grad, br.grad, be.grad]
+    for a, w in zip(got, want):
+        assert a.shape == w.shape
+        assert float((a - w).abs().max()) <= 1e-5 * max(1.0, float(w.abs().max()))
+    # only one of the two outputs used downstream (the other gradient arrives as None)
+    for p in (Wr, br, be):
+        p.grad = None
+    r3, _ = ops.Routing.apply(cov, Wr, br, be)
+    (r3 * gr).sum().backward()
+    g3 = Wr.grad.clone()
+    Wr.grad = None
+    (torch.sigmoid(torch.nn.functional.linear(cov, Wr, br)) * gr).sum().backward()
+    assert float((g3 - Wr.grad).abs().max()) <= 1e-5 * max(1.0, float(Wr.grad.abs().max()))
