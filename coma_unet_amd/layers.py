@@ -21,7 +21,11 @@ from .ops import Out
 class Config:
     """Shared by every layer of one model."""
 
-    def __init__(self, compute_dtype=torch.float32, conv_algo=0, bn_updates_per_forward=1):
+    def __init__(self, compute_dtype=torch.float32, conv_algo=0, bn_updates_per_forward=1, zero_bias_grad_under_norm=True):
+        # A convolution bias that feeds BatchNorm(train)/InstanceNorm is removed again by the normalisation's mean
+        # subtraction: its gradient is identically zero.  True returns exact zeros; False reduces dy over the voxels
+        # like the reference's autograd does (one more pass over dy per layer, producing rounding noise).
+        self.zero_bias_grad_under_norm = zero_bias_grad_under_norm
         self.compute_dtype = compute_dtype
         self.conv_algo = conv_algo            # 0 auto, 1 direct VALU fp32, 2 MFMA bf16
         self.bn_updates_per_forward = bn_updates_per_forward
@@ -109,9 +113,9 @@ def conv_plain(cfg, x, conv: nn.Module, ksize, stride, transposed, out=None, nor
     n_out = conv.weight.shape[1] if transposed else conv.weight.shape[0]
     a_f, a_d = ops.pick_algo(x.shape, x.dtype, n_out, ksize, stride, transposed, False, x.device, cfg.conv_algo)
     need_dx = x.requires_grad
-    wk_f, wk_d = ops.PrepWeights.apply(conv.weight, None, transposed, _wdtype(a_f), _wdtype(a_d) if need_dx else None)
-    return ops.Conv.apply(x, wk_f, wk_d, conv.bias, ksize, stride, transposed, False, cfg.conv_algo,
-                          Out(out) if out is not None else None, norm)
+    return ops.ConvLayer.apply(x, conv.weight, None, conv.bias, ksize, stride, transposed, cfg.conv_algo,
+                               Out(out) if out is not None else None, norm, _wdtype(a_f), _wdtype(a_d) if need_dx else None,
+                               cfg.zero_bias_grad_under_norm)
 
 
 class Convolution(nn.Module):
@@ -182,9 +186,9 @@ def conv_cond(cfg, x, cc: CondConv3d, covariate, out=None, norm=None):
     a_f, a_d = ops.pick_algo(x.shape, x.dtype, cc.out_channels, cc.kernel_size, cc.stride, cc.is_transposed, True,
                              x.device, cfg.conv_algo)
     need_dx = x.requires_grad
-    wk_f, wk_d = ops.PrepWeights.apply(cc.weight, r, cc.is_transposed, _wdtype(a_f), _wdtype(a_d) if need_dx else None)
-    return ops.Conv.apply(x, wk_f, wk_d, bias, cc.kernel_size, cc.stride, cc.is_transposed, True, cfg.conv_algo,
-                          Out(out) if out is not None else None, norm)
+    return ops.ConvLayer.apply(x, cc.weight, r, bias, cc.kernel_size, cc.stride, cc.is_transposed, cfg.conv_algo,
+                               Out(out) if out is not None else None, norm, _wdtype(a_f), _wdtype(a_d) if need_dx else None,
+                               cfg.zero_bias_grad_under_norm)
 
 
 class CondConvolution(nn.Module):

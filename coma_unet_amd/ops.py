@@ -108,42 +108,61 @@ class GradSink:
 # --------------------------------------------------------------------------------------
 # weights: CondConv expert mixing + kernel-layout cast
 # --------------------------------------------------------------------------------------
+def _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype):
+    """-> wk_f [Bw, taps, Cout, Cin], wk_d [Bw, taps, Cin, Cout] or None, r (fp32, contiguous) or None, meta."""
+    has_e = r is not None
+    m = master if has_e else master.unsqueeze(0)
+    assert m.is_contiguous() and m.dtype == torch.float32
+    E, A, Bc = m.shape[0], m.shape[1], m.shape[2]
+    taps = m.shape[3] * m.shape[4] * m.shape[5]
+    cout, cin = (Bc, A) if transposed else (A, Bc)
+    se = A * Bc * taps
+    if transposed:      # master [ci][co][tap]
+        sn_f, sc_f = taps, cout * taps
+    else:               # master [co][ci][tap]
+        sn_f, sc_f = cin * taps, taps
+    Bw = r.shape[0] if has_e else 1
+    rr = r.contiguous().float() if has_e else None
+    dev = master.device
+    wk_f = _new((Bw, taps, cout, cin), fwd_dtype, dev)
+    check(lib.coma_weight_prep(ptr(m), ptr(rr), E, Bw, cout, cin, taps, se, sn_f, sc_f, ptr(wk_f),
+                               L.dtype_code(fwd_dtype), L.stream()), "coma_weight_prep")
+    wk_d = None
+    if dgrad_dtype is not None:
+        wk_d = _new((Bw, taps, cin, cout), dgrad_dtype, dev)
+        check(lib.coma_weight_prep(ptr(m), ptr(rr), E, Bw, cin, cout, taps, se, sc_f, sn_f, ptr(wk_d),
+                                   L.dtype_code(dgrad_dtype), L.stream()), "coma_weight_prep")
+    return wk_f, wk_d, rr, (has_e, E, Bw, cout, cin, taps, se, sn_f, sc_f)
+
+
+def _prep_bwd(dwk, master, rr, meta, p_master):
+    """fp32 dwk [Bw, taps, Cout, Cin] -> (dmaster or None when written through to p_master.grad, dr or None)."""
+    has_e, E, Bw, cout, cin, taps, se, sn_f, sc_f = meta
+    sink = GradSink.slot(p_master)
+    dmaster = sink if sink is not None else torch.empty_like(master)
+    dr = _f32((Bw, E), master.device) if has_e else None
+    check(lib.coma_weight_prep_bwd(ptr(dwk), ptr(master), ptr(rr), E, Bw, cout, cin, taps, se, sn_f, sc_f,
+                                   ptr(dmaster), ptr(dr), L.stream()), "coma_weight_prep_bwd")
+    return (None if sink is not None else dmaster), dr
+
+
 class PrepWeights(Function):
     """master ([E,] A, B, k,k,k) fp32 (+ routing r (Bw, E)) -> (wk_fwd, wk_dgrad).
 
     wk_fwd [Bw, taps, Cout, Cin] feeds the forward gather, wk_dgrad [Bw, taps, Cin, Cout]
     the data-gradient gather; dtypes are chosen by the conv algo (fp32 direct / bf16 MFMA).
+    (Stand-alone form, used by the op tests; the model runs ConvLayer, which keeps the fp32 weight
+    gradient inside one autograd node.)
     """
 
     @staticmethod
     def forward(ctx, master, r, transposed, fwd_dtype, dgrad_dtype):
         ctx.set_materialize_grads(False)
         ctx.p_master = master
-        has_e = r is not None
-        m = master if has_e else master.unsqueeze(0)
-        assert m.is_contiguous() and m.dtype == torch.float32
-        E, A, Bc = m.shape[0], m.shape[1], m.shape[2]
-        taps = m.shape[3] * m.shape[4] * m.shape[5]
-        cout, cin = (Bc, A) if transposed else (A, Bc)
-        se = A * Bc * taps
-        if transposed:      # master [ci][co][tap]
-            sn_f, sc_f = taps, cout * taps
-        else:               # master [co][ci][tap]
-            sn_f, sc_f = cin * taps, taps
-        Bw = r.shape[0] if has_e else 1
-        rr = r.contiguous().float() if has_e else None
-        dev = master.device
-        wk_f = _new((Bw, taps, cout, cin), fwd_dtype, dev)
-        check(lib.coma_weight_prep(ptr(m), ptr(rr), E, Bw, cout, cin, taps, se, sn_f, sc_f, ptr(wk_f),
-                                   L.dtype_code(fwd_dtype), L.stream()), "coma_weight_prep")
-        wk_d = None
-        if dgrad_dtype is not None:
-            wk_d = _new((Bw, taps, cin, cout), dgrad_dtype, dev)
-            check(lib.coma_weight_prep(ptr(m), ptr(rr), E, Bw, cin, cout, taps, se, sc_f, sn_f, ptr(wk_d),
-                                       L.dtype_code(dgrad_dtype), L.stream()), "coma_weight_prep")
+        wk_f, wk_d, rr, ctx.meta = _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype)
+        if wk_d is not None:
             ctx.mark_non_differentiable(wk_d)
         ctx.save_for_backward(master, rr)
-        ctx.meta = (has_e, E, Bw, cout, cin, taps, se, sn_f, sc_f)
         return wk_f, wk_d
 
     @staticmethod
@@ -151,14 +170,8 @@ class PrepWeights(Function):
         if dwk_f is None:
             return None, None, None, None, None
         master, rr = ctx.saved_tensors
-        has_e, E, Bw, cout, cin, taps, se, sn_f, sc_f = ctx.meta
-        dwk = dwk_f.contiguous().float()
-        sink = GradSink.slot(ctx.p_master)
-        dmaster = sink if sink is not None else torch.empty_like(master)
-        dr = _f32((Bw, E), master.device) if has_e else None
-        check(lib.coma_weight_prep_bwd(ptr(dwk), ptr(master), ptr(rr), E, Bw, cout, cin, taps, se, sn_f, sc_f,
-                                       ptr(dmaster), ptr(dr), L.stream()), "coma_weight_prep_bwd")
-        return (None if sink is not None else dmaster), dr, None, None, None
+        dmaster, dr = _prep_bwd(dwk_f.contiguous().float(), master, rr, ctx.meta, ctx.p_master)
+        return dmaster, dr, None, None, None
 
 
 class Routing(Function):
@@ -224,78 +237,136 @@ def pick_algo(x_shape, x_dtype, n_out, ksize, stride, transposed, per_sample, de
     return a_f, a_d
 
 
+def _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm):
+    """One forward launch; with `norm` the (mean, rstd) of the normalisation that follows come out of the same pass."""
+    B, Do, Ho, Wo = conv_out_grid(x.shape, ksize, stride, form == 1)
+    n = wk_f.shape[2]
+    y = out.t if out is not None else _new((B, Do, Ho, Wo, n), x.dtype, x.device)
+    b = bias.contiguous().float() if bias is not None else None
+    kind = conv_class("mfma" if wk_f.dtype == torch.bfloat16 else "direct", x.shape[4], n)
+    d = _desc(ksize, stride, form, per_sample, algo)
+    tag = (tuple(x.shape), n, ksize, stride, form)
+    if norm is None:
+        KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
+                        lambda: check(lib.coma_conv_fwd(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), ct(y),
+                                                        L.stream()), "coma_conv_fwd"), tag=tag)
+        return y, None, None
+    mode, eps, rmean, rvar, momentum = norm
+    G = B if mode == L.NORM_INSTANCE else 1
+    mean, rstd = _f32((G, n), x.device), _f32((G, n), x.device)
+    cy = ct(y)
+    ws = workspace(lib.coma_norm_ws_bytes(cy), x.device)
+    KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
+                    lambda: check(lib.coma_conv_fwd_norm_stats(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), cy,
+                                                               mode, eps, ptr(mean), ptr(rstd), ptr(rmean), ptr(rvar),
+                                                               momentum, ptr(ws), ws.numel(), L.stream()),
+                                  "coma_conv_fwd_norm_stats"), tag=tag)
+    return y, mean, rstd
+
+
+def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_dx, need_dw, bias_mode, p_bias):
+    """-> dx, dwk (fp32, kernel layout), dbias (None when absent, written through, or identically zero).
+    bias_mode: 0 no bias, 1 reduce dy over the voxels, 2 the bias feeds a mean-removing normalisation (its gradient is
+    identically zero: exact zeros are returned instead of a reduction of rounding noise)."""
+    dx = dwk = dbias = None
+    s = L.stream()
+    tag = (tuple(x.shape), dy.shape[4], ksize, stride, form)
+    if need_dx:
+        assert wk_d is not None, "data gradient requested but dgrad weights were not prepared"
+        dx = torch.empty_like(x) if x.is_contiguous() else _new(x.shape, x.dtype, x.device)
+        KernelTimer.run("conv_dgrad", conv_class("mfma" if wk_d.dtype == torch.bfloat16 else "direct", dy.shape[4], x.shape[4]),
+                        conv_flops(dy.shape, dx.shape, ksize, stride),
+                        lambda: check(lib.coma_conv_fwd(_desc(ksize, stride, 1 - form, per_sample, algo), ct(dy),
+                                                        ptr(wk_d), L.dtype_code(wk_d.dtype), None, ct(dx), s),
+                                      "coma_conv_fwd(dgrad)"), tag=tag)
+    if need_dw:
+        d = _desc(ksize, stride, form, per_sample, algo)
+        cx, cdy = ct(x), ct(dy)
+        ws = workspace(lib.coma_conv_wgrad_ws_bytes(d, cx, cdy), x.device)
+        dwk = _f32(wshape, x.device)
+        bshape = (x.shape[0], wshape[2]) if per_sample else (wshape[2],)
+        dbias_k = None
+        if bias_mode == 1:
+            sink = GradSink.slot(p_bias)
+            dbias_k = sink if sink is not None else _f32(bshape, x.device)
+            dbias = None if sink is not None else dbias_k
+        elif bias_mode == 2 and not per_sample:   # (per-sample: the routing node receives None = zero)
+            sink = GradSink.slot(p_bias)          # the flat gradient buffer was zeroed by zero_grad(): nothing to write
+            dbias = None if sink is not None else torch.zeros(bshape, dtype=torch.float32, device=x.device)
+        walgo = conv_class("mfma" if lib.coma_conv_wgrad_algo(d, cx, cdy) == 2 else "direct", x.shape[4], dy.shape[4])
+        KernelTimer.run("conv_wgrad", walgo, conv_flops(x.shape, dy.shape, ksize, stride),
+                        lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias_k), ptr(ws), ws.numel(), s),
+                                      "coma_conv_wgrad"), tag=tag)
+    return dx, dwk, dbias
+
+
 class Conv(Function):
-    """y = conv(x).  With `norm` = (mode, eps, running_mean, running_var, momentum) the statistics of the
-    BatchNorm(train)/InstanceNorm that follows are produced in the same pass (epilogue-fused where the kernel
-    supports it) and returned as (y, mean, rstd)."""
+    """y = conv(x) on prepared kernel-layout weights (stand-alone form, used by the op tests).  With `norm` =
+    (mode, eps, running_mean, running_var, momentum) the statistics of the BatchNorm(train)/InstanceNorm that
+    follows are produced in the same pass (epilogue-fused where the kernel supports it) and returned as
+    (y, mean, rstd)."""
 
     @staticmethod
     def forward(ctx, x, wk_f, wk_d, bias, ksize, stride, transposed, per_sample, algo, out, norm=None):
         ctx.set_materialize_grads(False)
         ctx.p_bias = bias if not per_sample else None
-        B, Do, Ho, Wo = conv_out_grid(x.shape, ksize, stride, transposed)
-        n = wk_f.shape[2]
-        y = out.t if out is not None else _new((B, Do, Ho, Wo, n), x.dtype, x.device)
         form = 1 if transposed else 0
-        b = bias.contiguous().float() if bias is not None else None
-        kind = conv_class("mfma" if wk_f.dtype == torch.bfloat16 else "direct", x.shape[4], n)
-        d = _desc(ksize, stride, form, per_sample, algo)
+        y, mean, rstd = _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm)
         ctx.save_for_backward(x, wk_d)
         ctx.meta = (ksize, stride, form, per_sample, algo, bias is not None, tuple(wk_f.shape))
         if norm is None:
-            KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
-                            lambda: check(lib.coma_conv_fwd(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), ct(y),
-                                                            L.stream()), "coma_conv_fwd"),
-                            tag=(tuple(x.shape), n, ksize, stride, form))
             return y
-        mode, eps, rmean, rvar, momentum = norm
-        G = B if mode == L.NORM_INSTANCE else 1
-        mean, rstd = _f32((G, n), x.device), _f32((G, n), x.device)
-        cy = ct(y)
-        ws = workspace(lib.coma_norm_ws_bytes(cy), x.device)
-        KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
-                        lambda: check(lib.coma_conv_fwd_norm_stats(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), cy,
-                                                                   mode, eps, ptr(mean), ptr(rstd), ptr(rmean), ptr(rvar),
-                                                                   momentum, ptr(ws), ws.numel(), L.stream()),
-                                      "coma_conv_fwd_norm_stats"),
-                        tag=(tuple(x.shape), n, ksize, stride, form))
         ctx.mark_non_differentiable(mean, rstd)
         return y, mean, rstd
 
     @staticmethod
     def backward(ctx, dy, *_unused):
-        x, wk_d = ctx.saved_tensors
-        ksize, stride, form, per_sample, algo, has_bias, wshape = ctx.meta
-        dx = dwk = dbias = None
         if dy is None:
             return (None,) * 11
-        bias_sunk = False
-        s = L.stream()
-        if ctx.needs_input_grad[0]:
-            assert wk_d is not None, "data gradient requested but dgrad weights were not prepared"
-            dx = torch.empty_like(x) if x.is_contiguous() else _new(x.shape, x.dtype, x.device)
-            KernelTimer.run("conv_dgrad", conv_class("mfma" if wk_d.dtype == torch.bfloat16 else "direct", dy.shape[4], x.shape[4]),
-                            conv_flops(dy.shape, dx.shape, ksize, stride),
-                            lambda: check(lib.coma_conv_fwd(_desc(ksize, stride, 1 - form, per_sample, algo), ct(dy),
-                                                            ptr(wk_d), L.dtype_code(wk_d.dtype), None, ct(dx), s),
-                                          "coma_conv_fwd(dgrad)"),
-                            tag=(tuple(x.shape), dy.shape[4], ksize, stride, form))
-        if ctx.needs_input_grad[1]:
-            d = _desc(ksize, stride, form, per_sample, algo)
-            cx, cdy = ct(x), ct(dy)
-            nb = lib.coma_conv_wgrad_ws_bytes(d, cx, cdy)
-            ws = workspace(nb, x.device)
-            dwk = _f32(wshape, x.device)
-            if has_bias:
-                sink = GradSink.slot(ctx.p_bias)
-                bias_sunk = sink is not None
-                dbias = sink if bias_sunk else _f32((x.shape[0], wshape[2]) if per_sample else (wshape[2],), x.device)
-            walgo = conv_class("mfma" if lib.coma_conv_wgrad_algo(d, cx, cdy) == 2 else "direct", x.shape[4], dy.shape[4])
-            KernelTimer.run("conv_wgrad", walgo, conv_flops(x.shape, dy.shape, ksize, stride),
-                            lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias), ptr(ws), ws.numel(), s),
-                                          "coma_conv_wgrad"),
-                            tag=(tuple(x.shape), dy.shape[4], ksize, stride, form))
-        return dx, dwk, None, (None if bias_sunk else dbias), None, None, None, None, None, None, None
+        x, wk_d = ctx.saved_tensors
+        ksize, stride, form, per_sample, algo, has_bias, wshape = ctx.meta
+        dx, dwk, dbias = _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, ctx.needs_input_grad[0],
+                                   ctx.needs_input_grad[1], 1 if has_bias else 0, ctx.p_bias)
+        return dx, dwk, None, dbias, None, None, None, None, None, None, None
+
+
+class ConvLayer(Function):
+    """The model's convolution node: expert mix / re-layout of the fp32 master weights + the convolution, forward and
+    backward, as ONE autograd node -- the fp32 kernel-layout weight gradient never crosses an autograd edge (where it
+    would be cast to the bf16 dtype of the prepared weights and back).
+    master ([E,] A, B, k,k,k); r (B, E) routing or None; bias (Cout,) / per-sample (B, Cout) or None."""
+
+    @staticmethod
+    def forward(ctx, x, master, r, bias, ksize, stride, transposed, algo, out, norm, fwd_dtype, dgrad_dtype, bias_zero_grad):
+        ctx.set_materialize_grads(False)
+        per_sample = r is not None
+        form = 1 if transposed else 0
+        wk_f, wk_d, rr, pmeta = _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype)
+        y, mean, rstd = _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm)
+        ctx.save_for_backward(x, wk_d, master, rr)
+        ctx.p_master, ctx.p_bias = master, (bias if not per_sample else None)
+        # per-sample biases survive a BATCH norm (only their batch mean is removed); an instance norm removes them
+        removed = norm is not None and (not per_sample or norm[0] == L.NORM_INSTANCE)
+        bias_mode = 0 if bias is None else (2 if (bias_zero_grad and removed) else 1)
+        ctx.meta = (ksize, stride, form, per_sample, algo, bias_mode, tuple(wk_f.shape), pmeta)
+        if norm is None:
+            return y
+        ctx.mark_non_differentiable(mean, rstd)
+        return y, mean, rstd
+
+    @staticmethod
+    def backward(ctx, dy, *_unused):
+        if dy is None:
+            return (None,) * 13
+        x, wk_d, master, rr = ctx.saved_tensors
+        ksize, stride, form, per_sample, algo, bias_mode, wshape, pmeta = ctx.meta
+        need_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dwk, dbias = _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, ctx.needs_input_grad[0],
+                                   need_dw, bias_mode, ctx.p_bias)
+        dmaster = dr = None
+        if need_dw:
+            dmaster, dr = _prep_bwd(dwk, master, rr, pmeta, ctx.p_master)
+        return (dx, dmaster, dr, dbias) + (None,) * 9
 
 
 # --------------------------------------------------------------------------------------

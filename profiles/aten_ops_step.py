@@ -30,7 +30,7 @@ for (name, shp, where), n in sorted(cnt.items(), key=lambda kv: -kv[1])[:90]:
 ks = collections.Counter()
 for e in prof.events():
     if e.device_type == torch.autograd.DeviceType.CUDA:
-        ks[e.name[:60]] += 1
+        ks[e.name.replace('at::native::', '').replace('void ', '')[:110]] += 1
 print("--- device kernels:", sum(ks.values()))
-for k, n in ks.most_common(45):
+for k, n in ks.most_common(70):
     print(f"{n:4d} {k}")
