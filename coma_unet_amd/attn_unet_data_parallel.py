@@ -41,6 +41,14 @@ def to_external(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 4, 1, 2, 3)
 
 
+def _padded_input(x, dtype):
+    """(B, C, D, H, W) external volume -> internal (B, D, H, W, C) in the compute dtype, pitch-padded (ops._new)."""
+    v = to_internal(x)
+    xi = ops._new(tuple(v.shape), dtype, x.device)
+    xi.copy_(v)
+    return xi
+
+
 class UpBlock(nn.Module):
     """attn_unet_data_parallel.py:120-131 (conditional branch)."""
 
@@ -182,7 +190,7 @@ class ObservableAttentionUnet(nn.Module):
         return y, enc, dec
 
     def forward(self, x, covariate=None):
-        xi = to_internal(x).to(self.cfg.compute_dtype)
+        xi = _padded_input(x, self.cfg.compute_dtype)
         y, enc, dec = self._unet(xi, covariate)
         return to_external(y), [to_external(e) for e in enc], [to_external(d) for d in dec]
 
@@ -287,8 +295,8 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         B, D, H, W, _ = xi.shape
         dt, dev = xi.dtype, xi.device
         assert (D, H, W) == self.volume_shape, f"model built for {self.volume_shape}, got {(D, H, W)}"
-        cat_a = torch.empty((B, D, H, W, 2), dtype=dt, device=dev)   # cat((modulated_prompt, out)) :654
-        cat_b = torch.empty((B, D, H, W, 2), dtype=dt, device=dev)   # cat((out, fusion(...)))     :654
+        cat_a = ops._new((B, D, H, W, 2), dt, dev)   # cat((modulated_prompt, out)) :654
+        cat_b = ops._new((B, D, H, W, 2), dt, dev)   # cat((out, fusion(...)))     :654
         out_a, enc, dec = unet_out_dst(cat_a[..., 1:2])
         out_b = ops.Copy.apply(out_a, Out(cat_b[..., 0:1]))
         prior = self._priors(roi_pred_dicts, B, dev)
@@ -306,7 +314,7 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
     def forward(self, x, covariate=None, roi_pred_dicts=None, sample_roi_mask=None):
         if covariate is not None:     # one cast for every conditional layer (each routing reads fp32 covariates)
             covariate = covariate.to(device=x.device, dtype=torch.float32).contiguous()
-        xi = to_internal(x).to(self.cfg.compute_dtype)
+        xi = _padded_input(x, self.cfg.compute_dtype)
         cfgs = (self.cfg, self.cfg_heads) if self.training else ()
         for c in cfgs:
             c.begin_forward()

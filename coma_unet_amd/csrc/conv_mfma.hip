@@ -214,9 +214,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
   }
 }
 
-// 8 channels starting at `ptr`, of which `nvalid` exist; `vec` = 16-byte access is legal
+// 8 channels starting at `ptr`, of which `nvalid` exist; `vec` = 16-byte access is legal here: the base is 16-byte
+// aligned and the voxel pitch is a multiple of 8 channels, so the 8-channel piece lies inside the voxel's row even when
+// fewer than 8 of its channels belong to this tensor (a channel slice of a wider, padded buffer) -- those are masked off.
 __device__ __forceinline__ uint4 load8(const bf16_t* ptr, int nvalid, bool vec) {
-  if (vec && nvalid >= 8) return *reinterpret_cast<const uint4*>(ptr);
+  if (vec) {
+    uint4 v = *reinterpret_cast<const uint4*>(ptr);
+    if (nvalid < 8) {
+      auto m = [&](int j) -> unsigned { const int k = nvalid - 2 * j; return k >= 2 ? 0xffffffffu : (k == 1 ? 0xffffu : 0u); };
+      v.x &= m(0); v.y &= m(1); v.z &= m(2); v.w &= m(3);
+    }
+    return v;
+  }
   unsigned short e[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) e[j] = j < nvalid ? reinterpret_cast<const unsigned short*>(ptr)[j] : (unsigned short)0;
@@ -552,19 +561,30 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
       if (RESIDENT) {
         __syncthreads();
         if (has_next) load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0);
-#pragma unroll
-        for (int t = 0; t < 27; ++t) {
+        // LDS fragments are read one tap ahead into a second register set (hipcc otherwise issues each ds_read right
+        // before the MFMA that consumes it and waits lgkmcnt(0): the full LDS latency on every MFMA at 1-2 waves/SIMD)
+        uint4 wv[2][KS], xv[2][2][KS];
+        auto rd = [&](int t, int bf) {
           const int toff = (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * P;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const uint4 wv = *reinterpret_cast<const uint4*>(Wl + w_base + t * 32 * P + ks * 32);
-            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&wv);
+            wv[bf][ks] = *reinterpret_cast<const uint4*>(Wl + w_base + t * 32 * P + ks * 32);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const uint4 xv = *reinterpret_cast<const uint4*>(Hl + a_base[i] + toff + ks * 32);
-              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, *reinterpret_cast<const bf16x8_t*>(&xv), acc[i], 0, 0, 0);
-            }
+            for (int i = 0; i < 2; ++i) xv[bf][i][ks] = *reinterpret_cast<const uint4*>(Hl + a_base[i] + toff + ks * 32);
           }
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+          if (t + 1 < 27) rd(t + 1, (t + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wv[t & 1][ks]),
+                                                               *reinterpret_cast<const bf16x8_t*>(&xv[t & 1][i][ks]), acc[i], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       } else {
 #pragma unroll 1
@@ -576,19 +596,28 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
           else if (cc + 1 < nchunks) { load_w(cc * CK + CK, 0); load_halo(z0, y0, x0, cc * CK + CK); }
           else if (has_next) { load_w(0, 0); load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0); }
           const int gofs = g * HY * HX * P;
-#pragma unroll
-          for (int t = 0; t < 9; ++t) {
+          uint4 wv[2][KS], xv[2][2][KS];     // fragments one tap ahead (see the resident branch)
+          auto rd = [&](int t, int bf) {
             const int toff = ((t / 3) * HX + t % 3) * P;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-              const uint4 wv = *reinterpret_cast<const uint4*>(Wl + w_base + t * 32 * P + ks * 32);
-              const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&wv);
+              wv[bf][ks] = *reinterpret_cast<const uint4*>(Wl + w_base + t * 32 * P + ks * 32);
 #pragma unroll
-              for (int i = 0; i < 2; ++i) {
-                const uint4 xv = *reinterpret_cast<const uint4*>(Hl + a_base[i] + gofs + toff + ks * 32);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, *reinterpret_cast<const bf16x8_t*>(&xv), acc[i], 0, 0, 0);
-              }
+              for (int i = 0; i < 2; ++i) xv[bf][i][ks] = *reinterpret_cast<const uint4*>(Hl + a_base[i] + gofs + toff + ks * 32);
             }
+          };
+          rd(0, 0);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) rd(t + 1, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+              for (int i = 0; i < 2; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wv[t & 1][ks]),
+                                                                 *reinterpret_cast<const bf16x8_t*>(&xv[t & 1][i][ks]), acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -1106,41 +1135,66 @@ struct Wgrad2P {
   int ntx, nty, ntz, tiles_total, tiles_per_block, cblocks;
   int vec_n, vec_c;
   float* dwk; long wsb;
+  int nrep; long rep_stride;    // small outputs: blocks merge into one of nrep replicas (summed afterwards)
 };
 
 // One tile's MFMAs for the calling wave.  toff[t] = LDS byte offset of the wave's t-th tap (wave-uniform
 // scalars, so each gathered read costs one v_add with an SGPR operand; K-step offsets are scalars too and
 // the +4-voxel second read is an immediate).
-template <int HX, int HY>
-__device__ __forceinline__ void wgrad2_tile(const char* Dt, const char* Gt, int lane_d, int lane_g, const int (&toff)[7],
-                                            int ntap, f32x16_t (&acc)[7], int ks0, int ksd) {
+template <int HX, int HY, int NT>
+__device__ __forceinline__ void wgrad2_tile(const char* Dt, const char* Gt, int lane_d, int lane_g, const int (&toff)[NT],
+                                            int ntap, f32x16_t (&acc)[NT], int ks0, int ksd) {
   constexpr int PD = 64, PG = 64;
+  // Fragments are read one step ahead into a second register set: hipcc otherwise issues every transposed read right
+  // before its MFMA and waits lgkmcnt(0), exposing the LDS latency on each of them.
+  auto rd_d = [&](int ks) -> bf16x8_t {
+    const int z = ks >> 3, y = (ks >> 1) & 3, xh = ks & 1;
+    const char* dp = Dt + lane_d + ((z * 4 + y) * 32 + xh * 16) * PD;
+    const s4_t dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(dp));
+    const s4_t dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(dp + 4 * PD));
+    return (bf16x8_t){dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
+  };
+  auto rd_g = [&](int ks, int t) -> bf16x8_t {
+    const int z = ks >> 3, y = (ks >> 1) & 3, xh = ks & 1;
+    const char* gp = Gt + lane_g + ((z * HY + y) * HX + xh * 16) * PG;
+    const s4_t glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(gp + toff[t]));
+    const s4_t ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(gp + toff[t] + 4 * PG));
+    return (bf16x8_t){glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
+  };
+  // Every wave runs all NT column tiles (a wave with fewer valid ones recomputes tile 0 into an accumulator that is
+  // never stored): no wave-dependent control flow inside the pipeline, and the slowest wave has NT tiles anyway.
+  (void)ntap;
+  bf16x8_t df = rd_d(ks0), gf = rd_g(ks0, 0);
 #pragma unroll 2
   for (int ks = ks0; ks < 16; ks += ksd) {
     // K step ks = 16 consecutive x of row (z = ks >> 3, y = (ks >> 1) & 3), x half = ks & 1
-    const int z = ks >> 3, y = (ks >> 1) & 3, xh = ks & 1;
-    const char* dp = Dt + lane_d + ((z * 4 + y) * 32 + xh * 16) * PD;
-    const char* gp = Gt + lane_g + ((z * HY + y) * HX + xh * 16) * PG;
-    const s4_t dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(dp));
-    const s4_t dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(dp + 4 * PD));
-    const bf16x8_t df = (bf16x8_t){dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
+    const int kn = ks + ksd < 16 ? ks + ksd : ks;      // (the last step re-reads itself: harmless, keeps the loop uniform)
+    bf16x8_t dn = df;
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
-      if (t < ntap) {
-        const s4_t glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(gp + toff[t]));
-        const s4_t ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(gp + toff[t] + 4 * PG));
-        const bf16x8_t gf = (bf16x8_t){glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, gf, acc[t], 0, 0, 0);
-      }
+    for (int t = 0; t < NT; ++t) {
+      bf16x8_t gn;
+      if (t + 1 < NT) gn = rd_g(ks, t + 1);
+      else { dn = rd_d(kn); gn = rd_g(kn, 0); }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, gf, acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      gf = gn;
     }
+    df = dn;
   }
 }
 
 // VEC=1: every staged piece is a legal, fully valid 16-byte load; OCC = blocks per CU; K = kernel size (3 or 1:
 // for 1x1x1 there is one tap and the four waves share it by K step instead of by tap).
-template <int VEC, int OCC, int K>
+// PK = taps packed side by side in the 32 MFMA columns when the layer has few input channels: 1 (C > 16: one tap,
+// 32 channels), 2 (C <= 16: column j = tap kx0 + (j >> 4), channel j & 15), 4 (C <= 8: tap kx0 + (j >> 3), channel
+// j & 7).  A packed tile is a (kz, ky) row of the kernel: {kx 0,1} {kx 2,-} for PK = 2 (18 MFMA tiles instead of 27),
+// {kx 0,1,2,-} for PK = 4 (9 tiles); the "-" columns multiply the voxel one past kx = 2 and are never stored.  The
+// x-shifted neighbour is a per-lane constant in the transposed read's address, so the inner loop is unchanged.
+template <int VEC, int OCC, int K, int PK>
 __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
   constexpr int PADK = (K - 1) / 2;
+  constexpr int NTILE = K == 1 ? 1 : (PK == 1 ? 27 : PK == 2 ? 18 : 9), NT = (NTILE + 3) / 4;
   constexpr int TX = 32, TY = 4, TZ = 2, TM = TX * TY * TZ, HX = TX + K - 1, HY = TY + K - 1, HZ = TZ + K - 1, HV = HX * HY * HZ;
   constexpr int NDP = TM * 4, NGP = HV * 4;                     // 16-byte pieces (dense, halo)
   constexpr int DIT = NDP / 256, GIT = (NGP + 255) / 256;        // 4 and 13 per thread
@@ -1161,9 +1215,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
   // zero the whole LDS image once: padding channels / never-staged pieces stay zero
   for (int i = tid; i < NDP + NGP; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
 
-  f32x16_t acc[7];
+  f32x16_t acc[NT];
 #pragma unroll
-  for (int t = 0; t < 7; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
@@ -1171,15 +1225,20 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
   const int vrow = 8 * (g16 >> 1) + q;                          // voxel within a 16-voxel K step
   const int chan_b = ((g16 & 1) * 16 + 4 * pp) * 2;
   const int lane_d = vrow * 64 + chan_b;
-  const int lane_g = vrow * 64 + chan_b;
+  // gathered operand: which 4-channel piece of which x-neighbour this lane feeds into the 16-lane transpose
+  const int chunk = (g16 & 1) * 4 + pp;
+  const int lane_g = PK == 1 ? vrow * 64 + chan_b
+                   : PK == 2 ? (vrow + (chunk >> 2)) * 64 + (chunk & 3) * 8
+                             : (vrow + (chunk >> 1)) * 64 + (chunk & 1) * 8;
 
-  int toff[7];
+  int toff[NT];
 #pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int tap = wid + 4 * t;
-    toff[t] = K == 1 ? 0 : __builtin_amdgcn_readfirstlane((((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64);
+  for (int t = 0; t < NT; ++t) {
+    const int i = wid + 4 * t < NTILE ? wid + 4 * t : 0;   // MFMA tile index: tap (PK 1), (row, kx pair) (PK 2), row (PK 4)
+    const int row = PK == 1 ? i / 3 : PK == 2 ? i >> 1 : i, kx0 = PK == 1 ? i % 3 : PK == 2 ? (i & 1) * 2 : 0;
+    toff[t] = K == 1 ? 0 : __builtin_amdgcn_readfirstlane((((row / 3) * HY + row % 3) * HX + kx0) * 64);
   }
-  const int ntap = K == 1 ? 1 : (wid == 3 ? 6 : 7);
+  const int ntap = K == 1 ? 1 : (NTILE - wid + 3) / 4;
 
   const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * p.tiles_per_block;
   int tile_end = tile_begin + p.tiles_per_block;
@@ -1236,22 +1295,27 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
     __syncthreads();     // previous tile's LDS reads are done
     store_tile();
     __syncthreads();
-    if (OCC == 1) { if (nt < tile_end) load_tile(ntix * TX, ntiy * TY, ntiz * TZ); }   // prefetch under the MFMAs
-    wgrad2_tile<HX, HY>(Dt, Gt, lane_d, lane_g, toff, ntap, acc, K == 1 ? wid : 0, K == 1 ? 4 : 1);
-    if (OCC != 1) { if (nt < tile_end) load_tile(ntix * TX, ntiy * TY, ntiz * TZ); }   // the co-resident block covers this latency
+    constexpr bool EARLY = OCC == 1 || PK > 1 || K == 1;    // few accumulators: room to hold the next tile in registers
+    if (EARLY) { if (nt < tile_end) load_tile(ntix * TX, ntiy * TY, ntiz * TZ); }   // prefetch under the MFMAs
+    wgrad2_tile<HX, HY, NT>(Dt, Gt, lane_d, lane_g, toff, ntap, acc, K == 1 ? wid : 0, K == 1 ? 4 : 1);
+    if (!EARLY) { if (nt < tile_end) load_tile(ntix * TX, ntiy * TY, ntiz * TZ); }  // the co-resident block covers this latency
     tile = nt;
   }
   // ---- merge into dwk[b][tap][n][c] ----
-  float* wout = p.dwk + (long)b * p.wsb;
+  float* wout = p.dwk + (long)b * p.wsb + (long)(blockIdx.x % (unsigned)p.nrep) * p.rep_stride;
   const int fr = lane & 31, fh = lane >> 5;
+  const int sub = PK == 1 ? 0 : PK == 2 ? fr >> 4 : fr >> 3;           // x-neighbour of this lane's column
+  const int cc = PK == 1 ? fr : PK == 2 ? (fr & 15) : (fr & 7);
 #pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int tap = K == 1 ? 0 : wid + 4 * t;
-    if (t < ntap) {
+  for (int t = 0; t < NT; ++t) {
+    const int i = wid + 4 * t;
+    const int row = PK == 1 ? i / 3 : PK == 2 ? i >> 1 : i, kx = (PK == 1 ? i % 3 : PK == 2 ? (i & 1) * 2 : 0) + sub;
+    const int tap = K == 1 ? 0 : row * 3 + kx;
+    if (t < ntap && kx < 3) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        const int c = c0 + fr;
+        const int c = c0 + cc;
         if (n < p.N && c < p.C) atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, acc[t][e]);
       }
     }
@@ -1263,7 +1327,24 @@ static bool wgrad2_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_
          x->W >= 32 && (long)t_vox(x) * x->ld < (1L << 31) && (long)t_vox(dy) * dy->ld < (1L << 31);
 }
 
-static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s) {
+// Small weight tensors (the 1..16-channel layers, 1x1x1 gates): a thousand blocks merging into a few cache lines
+// serialise in the L2 atomic unit (1 -> 32 channels at 128^3: 520 us, of which ~400 us were atomics).  Their blocks
+// merge into WGRAD_NREP replicas in the workspace instead, summed by one tiny kernel.
+#define WGRAD_NREP 64
+#define WGRAD_REP_MAX_ELEMS 16384
+static long wgrad_out_elems(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  return (long)d->ksize * d->ksize * d->ksize * dy->C * x->C * (d->per_sample_w ? x->B : 1);
+}
+__global__ __launch_bounds__(256) void wgrad_replica_sum_k(const float* __restrict__ rep, int nrep, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int r = 0; r < nrep; ++r) a += rep[(long)r * n + i];
+  out[i] = a;
+}
+
+static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws,
+                            size_t ws_bytes, hipStream_t s) {
   Wgrad2P p;
   p.dyp = (const bf16_t*)dy->data; p.ldn = (int)dy->ld; p.sbn = dy->sb;
   p.xp = (const bf16_t*)x->data; p.ldc = (int)x->ld; p.sbc = x->sb;
@@ -1282,24 +1363,36 @@ static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const
   const long taps = (long)d->ksize * d->ksize * d->ksize;
   p.dwk = dwk; p.wsb = d->per_sample_w ? taps * p.N * p.C : 0;
   const long wsz = taps * p.N * p.C * (d->per_sample_w ? x->B : 1);
-  if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
-  const size_t lds = (size_t)(256 + (d->ksize == 3 ? 816 : 256)) * 64;
+  const bool replicas = wsz <= WGRAD_REP_MAX_ELEMS && ws && ws_bytes >= sizeof(float) * wsz * WGRAD_NREP;
+  p.nrep = replicas ? WGRAD_NREP : 1;
+  p.rep_stride = replicas ? wsz : 0;
+  if (replicas) p.dwk = (float*)ws;
+  if (hipMemsetAsync(p.dwk, 0, sizeof(float) * wsz * p.nrep, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  const size_t lds = (size_t)(256 + (d->ksize == 3 ? 816 + 1 : 256)) * 64;   // +1 row: the unused packed column reads one voxel past the halo
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<0, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<0, 2, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<1, 2, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<0, 2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<1, 2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<0, 2, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad2_k<1, 2, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr = true;
   }
   const bool vec = p.vec_n && p.vec_c && p.N % 8 == 0 && p.C % 8 == 0;
   const dim3 grid((unsigned)chunks, (unsigned)pairs, (unsigned)x->B);
-  if (d->ksize == 1) {
-    if (vec) hipLaunchKernelGGL((conv_mfma_wgrad2_k<1, 2, 1>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((conv_mfma_wgrad2_k<0, 2, 1>), grid, dim3(256), lds, s, p);
-  } else {
-    if (vec) hipLaunchKernelGGL((conv_mfma_wgrad2_k<1, 2, 3>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((conv_mfma_wgrad2_k<0, 2, 3>), grid, dim3(256), lds, s, p);
-  }
+#define WG2(K_, PK_) do { if (vec) hipLaunchKernelGGL((conv_mfma_wgrad2_k<1, 2, K_, PK_>), grid, dim3(256), lds, s, p); \
+                          else hipLaunchKernelGGL((conv_mfma_wgrad2_k<0, 2, K_, PK_>), grid, dim3(256), lds, s, p); } while (0)
+  if (d->ksize == 1) WG2(1, 1);
+  else if (p.C <= 8) WG2(3, 4);
+  else if (p.C <= 16) WG2(3, 2);
+  else WG2(3, 1);
+#undef WG2
   COMA_LAUNCH_CHECK();
+  if (replicas) {
+    hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
+    COMA_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -1369,11 +1462,14 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
 bool conv_mfma_wgrad_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   return wgrad2_ok(d, x, dy) || wgrad_plan(d, x, dy).ok;
 }
-size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc*, const coma_tensor*, const coma_tensor*) { return 0; }
+size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  const long wsz = wgrad_out_elems(d, x, dy);
+  return wgrad2_ok(d, x, dy) && wsz <= WGRAD_REP_MAX_ELEMS ? sizeof(float) * wsz * WGRAD_NREP : 0;
+}
 
-int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void*, size_t,
+int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws, size_t ws_bytes,
                     hipStream_t s) {
-  if (wgrad2_ok(d, x, dy)) return conv_mfma_wgrad2(d, x, dy, dwk, s);
+  if (wgrad2_ok(d, x, dy)) return conv_mfma_wgrad2(d, x, dy, dwk, ws, ws_bytes, s);
   WgradPlan pl = wgrad_plan(d, x, dy);
   COMA_CHECK(pl.ok, "conv_mfma_wgrad: unsupported problem");
   pl.p.dwk = dwk;

@@ -211,7 +211,7 @@ extern "C" int coma_gate_mul_bwd(const coma_tensor* x, const coma_tensor* psi, c
 }
 
 // ---- ROI prior painting + prompt select ----
-struct RoiP { const float* roi; int64_t sbr; const void* x; int64_t sbx; const float* prior; const int32_t* ids; int n_roi;
+struct RoiP { const float* roi; int64_t sbr; const void* x; int64_t sbx, ldx; const float* prior; const int32_t* ids; int n_roi;
               const float* abeta; const float* pos; const float* neg; void* out; int64_t ldo, sbo; int64_t V; };
 
 __device__ __forceinline__ int roi_slot(const int32_t* ids, int n, float label) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void roi_paint_fwd_k(RoiP p) {
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < p.V; v += (int64_t)gridDim.x * 256) {
     float suvr = 0.f, sal = 0.f;
     const int slot = roi_slot(ids, p.n_roi, rb[v]);
-    if (slot >= 0 && !(ld_f(xb + v) < 1e-4f)) { suvr = pri[2 * slot]; sal = pri[2 * slot + 1]; }
+    if (slot >= 0 && !(ld_f(xb + v * p.ldx) < 1e-4f)) { suvr = pri[2 * slot]; sal = pri[2 * slot + 1]; }
     T* o = ob + v * p.ldo;
     st_f(o, prompt[v]); st_f(o + 1, sal); st_f(o + 2, suvr);   // cat((prompt, saliency, suvr)) :651
   }
@@ -250,10 +250,10 @@ extern "C" int coma_roi_paint_fwd(const coma_tensor* roi, const coma_tensor* x, 
                                   const float* neg_prompt, const coma_tensor* out3, void* stream) {
   COMA_CHECK(roi && x && out3 && roi->data && x->data && out3->data && prior && roi_ids && abeta && pos_prompt && neg_prompt,
              "roi_paint_fwd: null argument");
-  COMA_CHECK(roi->dtype == COMA_F32 && roi->C == 1 && roi->ld == 1 && x->C == 1 && x->ld == 1 && out3->C == 3 &&
+  COMA_CHECK(roi->dtype == COMA_F32 && roi->C == 1 && roi->ld == 1 && x->C == 1 && out3->C == 3 &&
              t_same_grid(roi, x) && t_same_grid(roi, out3) && x->dtype == out3->dtype, "roi_paint_fwd: shape/dtype mismatch");
   COMA_CHECK(n_roi > 0 && n_roi <= 64, "roi_paint_fwd: n_roi=%d out of range", n_roi);
-  RoiP p; p.roi = (const float*)roi->data; p.sbr = roi->sb; p.x = x->data; p.sbx = x->sb; p.prior = prior; p.ids = roi_ids;
+  RoiP p; p.roi = (const float*)roi->data; p.sbr = roi->sb; p.x = x->data; p.sbx = x->sb; p.ldx = x->ld; p.prior = prior; p.ids = roi_ids;
   p.n_roi = n_roi; p.abeta = abeta; p.pos = pos_prompt; p.neg = neg_prompt; p.out = out3->data; p.ldo = out3->ld;
   p.sbo = out3->sb; p.V = t_vox(roi);
   dim3 grid(ew_grid(p.V), roi->B);
@@ -293,7 +293,7 @@ extern "C" int coma_roi_paint_bwd(const coma_tensor* dout3, const float* abeta, 
 // ---- losses ----
 // partial[(b*nblk + blk)] = {sum mask, sum (p-g)^2 or |p-g|}
 template <typename T, int L1>
-__global__ __launch_bounds__(256) void loss_partial_k(const T* pred, int64_t sbp, const T* gt, int64_t sbg, const float* roi,
+__global__ __launch_bounds__(256) void loss_partial_k(const T* pred, int64_t sbp, int64_t ldp, const T* gt, int64_t sbg, const float* roi,
                                                       int64_t sbr, const int32_t* ids_g, const float* w_g, int n_roi,
                                                       int64_t V, double2* partial) {
   __shared__ int32_t ids[64];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void loss_partial_k(const T* pred, int64_t sbp
   __syncthreads();
   double sm = 0.0, se = 0.0;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
-    const float d = ld_f(pred + b * sbp + v) - ld_f(gt + b * sbg + v);
+    const float d = ld_f(pred + b * sbp + v * ldp) - ld_f(gt + b * sbg + v);
     se += L1 ? (double)fabsf(d) : (double)d * (double)d;
     if (roi) { const int slot = roi_slot(ids, n_roi, roi[b * sbr + v]); if (slot >= 0) sm += (double)w[slot]; }
   }
@@ -332,8 +332,8 @@ extern "C" size_t coma_loss_ws_bytes(const coma_tensor* pred) { return (size_t)p
 static int loss_fwd(const coma_tensor* pred, const coma_tensor* gt, const coma_tensor* roi, const int32_t* ids,
                     const float* w, int n_roi, float* loss, float* mask_mean, void* ws, size_t ws_bytes, hipStream_t s, int l1) {
   COMA_CHECK(pred && gt && pred->data && gt->data && loss && ws, "loss: null argument");
-  COMA_CHECK(t_same_grid(pred, gt) && pred->C == 1 && gt->C == 1 && pred->ld == 1 && gt->ld == 1 && pred->dtype == gt->dtype,
-             "loss: pred/gt must be single-channel contiguous volumes of equal shape");
+  COMA_CHECK(t_same_grid(pred, gt) && pred->C == 1 && gt->C == 1 && gt->ld == 1 && pred->dtype == gt->dtype,
+             "loss: pred/gt must be single-channel volumes of equal shape (gt contiguous)");
   COMA_CHECK(ws_bytes >= coma_loss_ws_bytes(pred), "loss: workspace too small");
   if (!l1) COMA_CHECK(roi && roi->data && roi->dtype == COMA_F32 && roi->C == 1 && roi->ld == 1 && t_same_grid(pred, roi) &&
                       ids && w && mask_mean && n_roi > 0 && n_roi <= 64, "roi_mse: bad roi arguments");
@@ -344,7 +344,7 @@ static int loss_fwd(const coma_tensor* pred, const coma_tensor* gt, const coma_t
   dim3 grid(nblk, pred->B);
   const float* rp = l1 ? nullptr : (const float*)roi->data;
   const int64_t sbr = l1 ? 0 : roi->sb;
-#define L(T, K) hipLaunchKernelGGL((loss_partial_k<T, K>), grid, dim3(256), 0, s, (const T*)pred->data, pred->sb, \
+#define L(T, K) hipLaunchKernelGGL((loss_partial_k<T, K>), grid, dim3(256), 0, s, (const T*)pred->data, pred->sb, pred->ld, \
                                    (const T*)gt->data, gt->sb, rp, sbr, ids, w, n_roi, V, (double2*)ws)
   if (pred->dtype == COMA_F32) { if (l1) L(float, 1); else L(float, 0); }
   else { if (l1) L(bf16_t, 1); else L(bf16_t, 0); }
@@ -366,25 +366,25 @@ extern "C" int coma_l1_fwd(const coma_tensor* pred, const coma_tensor* gt, float
 }
 
 template <typename T, int L1>
-__global__ __launch_bounds__(256) void loss_bwd_k(const T* pred, int64_t sbp, const T* gt, int64_t sbg, const float* gout,
-                                                  const float* mask_mean, T* dp, int64_t sbd, int64_t V) {
+__global__ __launch_bounds__(256) void loss_bwd_k(const T* pred, int64_t sbp, int64_t ldp, const T* gt, int64_t sbg, const float* gout,
+                                                  const float* mask_mean, T* dp, int64_t sbd, int64_t ldd, int64_t V) {
   const int b = blockIdx.y;
   const float scale = gout[b] * (L1 ? 1.f : mask_mean[b] * 2.f) / (float)V;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
-    const float d = ld_f(pred + b * sbp + v) - ld_f(gt + b * sbg + v);
+    const float d = ld_f(pred + b * sbp + v * ldp) - ld_f(gt + b * sbg + v);
     const float g = L1 ? (d > 0.f ? scale : (d < 0.f ? -scale : 0.f)) : scale * d;
-    st_f(dp + b * sbd + v, g);
+    st_f(dp + b * sbd + v * ldd, g);
   }
 }
 static int loss_bwd(const coma_tensor* pred, const coma_tensor* gt, const float* gout, const float* mask_mean,
                     const coma_tensor* dpred, hipStream_t s, int l1) {
   COMA_CHECK(pred && gt && dpred && pred->data && gt->data && dpred->data && gout && (l1 || mask_mean), "loss_bwd: null argument");
-  COMA_CHECK(t_same_grid(pred, gt) && t_same_grid(pred, dpred) && pred->C == 1 && pred->ld == 1 && gt->ld == 1 &&
-             dpred->ld == 1 && pred->dtype == gt->dtype && pred->dtype == dpred->dtype, "loss_bwd: shape/dtype mismatch");
+  COMA_CHECK(t_same_grid(pred, gt) && t_same_grid(pred, dpred) && pred->C == 1 && gt->ld == 1 &&
+             pred->dtype == gt->dtype && pred->dtype == dpred->dtype, "loss_bwd: shape/dtype mismatch");
   const int64_t V = t_vox(pred);
   dim3 grid(ew_grid(V), pred->B);
-#define L(T, K) hipLaunchKernelGGL((loss_bwd_k<T, K>), grid, dim3(256), 0, s, (const T*)pred->data, pred->sb, \
-                                   (const T*)gt->data, gt->sb, gout, mask_mean, (T*)dpred->data, dpred->sb, V)
+#define L(T, K) hipLaunchKernelGGL((loss_bwd_k<T, K>), grid, dim3(256), 0, s, (const T*)pred->data, pred->sb, pred->ld, \
+                                   (const T*)gt->data, gt->sb, gout, mask_mean, (T*)dpred->data, dpred->sb, dpred->ld, V)
   if (pred->dtype == COMA_F32) { if (l1) L(float, 1); else L(float, 0); }
   else { if (l1) L(bf16_t, 1); else L(bf16_t, 0); }
 #undef L

@@ -11,7 +11,7 @@
 // |(g-p)/g| where |g| > 1e-8 (else NaN, skipped).
 #define EV_K 8
 template <typename T>
-__global__ __launch_bounds__(256) void eval_stats_k(const T* pred, int64_t sbp, const T* gt, int64_t sbg, const float* roi,
+__global__ __launch_bounds__(256) void eval_stats_k(const T* pred, int64_t sbp, int64_t ldp, const T* gt, int64_t sbg, const float* roi,
                                                     int64_t sbr, const int32_t* ids_g, int n_roi, int64_t V, double* stats) {
   __shared__ int32_t ids[64];
   __shared__ double bins[64][EV_K];
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void eval_stats_k(const T* pred, int64_t sbp, 
   __syncthreads();
   double g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0;   // whole-volume bin in registers
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
-    const float p = ld_f(pred + b * sbp + v), g = ld_f(gt + b * sbg + v);
+    const float p = ld_f(pred + b * sbp + v * ldp), g = ld_f(gt + b * sbg + v);
     const float d = p - g;
     const float ad = fabsf(d);
     g0 += 1.0; g1 += ad; g2 += (double)d * d; g3 += g; g4 += (double)g * g; g5 += p;
@@ -51,9 +51,9 @@ __global__ __launch_bounds__(256) void eval_stats_k(const T* pred, int64_t sbp, 
 extern "C" int coma_eval_stats(const coma_tensor* pred, const coma_tensor* gt, const coma_tensor* roi, const int32_t* roi_ids,
                                int32_t n_roi, double* stats, void* stream) {
   COMA_CHECK(pred && gt && roi && pred->data && gt->data && roi->data && roi_ids && stats, "eval_stats: null argument");
-  COMA_CHECK(t_same_grid(pred, gt) && t_same_grid(pred, roi) && pred->C == 1 && gt->C == 1 && roi->C == 1 && pred->ld == 1 &&
+  COMA_CHECK(t_same_grid(pred, gt) && t_same_grid(pred, roi) && pred->C == 1 && gt->C == 1 && roi->C == 1 &&
              gt->ld == 1 && roi->ld == 1 && pred->dtype == gt->dtype && roi->dtype == COMA_F32,
-             "eval_stats: single-channel contiguous volumes of equal shape (roi fp32) expected");
+             "eval_stats: single-channel volumes of equal shape (gt, roi contiguous; roi fp32) expected");
   COMA_CHECK(n_roi > 0 && n_roi < 64, "eval_stats: n_roi=%d out of range", n_roi);
   hipStream_t s = (hipStream_t)stream;
   const int64_t V = t_vox(pred);
@@ -64,10 +64,10 @@ extern "C" int coma_eval_stats(const coma_tensor* pred, const coma_tensor* gt, c
   if (nblk < 1) nblk = 1;
   dim3 grid(nblk, pred->B);
   if (pred->dtype == COMA_F32)
-    hipLaunchKernelGGL(eval_stats_k<float>, grid, dim3(256), 0, s, (const float*)pred->data, pred->sb, (const float*)gt->data,
+    hipLaunchKernelGGL(eval_stats_k<float>, grid, dim3(256), 0, s, (const float*)pred->data, pred->sb, pred->ld, (const float*)gt->data,
                        gt->sb, (const float*)roi->data, roi->sb, roi_ids, n_roi, V, stats);
   else
-    hipLaunchKernelGGL(eval_stats_k<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)pred->data, pred->sb,
+    hipLaunchKernelGGL(eval_stats_k<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)pred->data, pred->sb, pred->ld,
                        (const bf16_t*)gt->data, gt->sb, (const float*)roi->data, roi->sb, roi_ids, n_roi, V, stats);
   COMA_LAUNCH_CHECK();
   return 0;

@@ -78,6 +78,12 @@ def conv_class(algo_name, cin, cout):
 
 
 def _new(shape, dtype, device):
+    """Activation buffer.  (B, D, H, W, C) volumes whose channel count is not a multiple of 8 (the 1..3-channel tensors of
+    the full-resolution tail) get a voxel pitch rounded up to 8 channels: every kernel takes the pitch `ld`, and 16-byte
+    aligned rows let the convolution staging use (masked) vector loads instead of per-element ones."""
+    if len(shape) == 5 and shape[4] % 8 != 0:
+        C = shape[4]
+        return torch.empty(tuple(shape[:4]) + ((C + 7) // 8 * 8,), dtype=dtype, device=device)[..., :C]
     return torch.empty(shape, dtype=dtype, device=device)
 
 
@@ -273,7 +279,7 @@ def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_d
     tag = (tuple(x.shape), dy.shape[4], ksize, stride, form)
     if need_dx:
         assert wk_d is not None, "data gradient requested but dgrad weights were not prepared"
-        dx = torch.empty_like(x) if x.is_contiguous() else _new(x.shape, x.dtype, x.device)
+        dx = _new(x.shape, x.dtype, x.device)
         KernelTimer.run("conv_dgrad", conv_class("mfma" if wk_d.dtype == torch.bfloat16 else "direct", dy.shape[4], x.shape[4]),
                         conv_flops(dy.shape, dx.shape, ksize, stride),
                         lambda: check(lib.coma_conv_fwd(_desc(ksize, stride, 1 - form, per_sample, algo), ct(dy),
