@@ -37,6 +37,7 @@ SIGNATURES = {
     "coma_abi_version": (_i32, []),
     "coma_last_error": (C.c_char_p, []),
     "coma_weight_prep": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
+    "coma_weight_prep_pair": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "coma_weight_prep_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     "coma_routing_fwd": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "coma_routing_bwd": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -59,6 +59,100 @@ extern "C" int coma_weight_prep(const float* master, const float* r, int32_t E, 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Tiled 27-tap variants.  The kernels above give each thread one (n, c) pair and its 27 contiguous taps: lanes are
+// 108 bytes (or a whole weight row) apart, every load instruction touches ~54 cache lines, and the mix ran at a
+// quarter of the HBM rate.  Here a block owns a 16 x 16 tile of (a, b) = (master dim 0, dim 1) pairs; each expert's
+// tile is 16 runs of 432 contiguous floats read with consecutive lanes on consecutive addresses, the mixed tile goes
+// through LDS once, and both kernel layouts ([tap][a][b] and [tap][b][a]) are written from the same pass in 16-element
+// rows.  (The same tiling applied to the backward kernel measured 2x SLOWER than the per-pair form below -- 2.07 vs
+// 1.10 ms per step -- and was dropped.)
+// ---------------------------------------------------------------------------------------
+#define WT_T 16
+#define WT_ROW (WT_T * 27)          // floats of one a-row of the tile
+#define WT_PITCH (WT_ROW + 1)       // LDS pitch of an a-row: odd, so column reads (fixed b, tap; a varies) are conflict-free
+#define WT_ELEMS (WT_T * WT_ROW)    // 6912 = 27 per thread
+
+__device__ __forceinline__ void wt_store(void* base, int dtype, int64_t idx, float v) {
+  if (dtype == COMA_F32) reinterpret_cast<float*>(base)[idx] = v;
+  else reinterpret_cast<bf16_t*>(base)[idx] = static_cast<bf16_t>(v);
+}
+
+template <int BB>
+__global__ __launch_bounds__(256) void weight_prep_tiled_k(const float* __restrict__ master, const float* __restrict__ r, int E,
+                                                           int bw0, int nb, int A, int Bd, int64_t se, void* out_ab, int dt_ab,
+                                                           void* out_ba, int dt_ba) {
+  __shared__ float tile[WT_T * WT_PITCH];
+  const int tid = threadIdx.x;
+  const int a0 = blockIdx.y * WT_T, b0 = blockIdx.x * WT_T;
+  const int bspan = (Bd - b0 < WT_T ? Bd - b0 : WT_T) * 27;      // valid floats of an a-row of this tile
+  float acc[BB][27];
+#pragma unroll
+  for (int b = 0; b < BB; ++b)
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[b][k] = 0.f;
+  for (int e = 0; e < E; ++e) {
+    float rb[BB];
+#pragma unroll
+    for (int b = 0; b < BB; ++b) rb[b] = (b < nb) ? (r ? r[(bw0 + b) * E + e] : 1.f) : 0.f;
+    const float* mp = master + e * se + ((int64_t)a0 * Bd + b0) * 27;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const int idx = tid + 256 * k, al = idx / WT_ROW, rem = idx - al * WT_ROW;
+      const float w = (a0 + al < A && rem < bspan) ? mp[(int64_t)al * Bd * 27 + rem] : 0.f;
+#pragma unroll
+      for (int b = 0; b < BB; ++b) acc[b][k] = fmaf(rb[b], w, acc[b][k]);
+    }
+  }
+  const int64_t AB = (int64_t)A * Bd;
+  const int col = tid & 15, rw = tid >> 4;        // output phase: 16 rows of 16 contiguous elements per sweep
+#pragma unroll
+  for (int b = 0; b < BB; ++b) {
+    if (b < nb) {                                  // (block-uniform)
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const int idx = tid + 256 * k, al = idx / WT_ROW;
+        tile[idx + al] = acc[b][k];                // al * WT_PITCH + rem
+      }
+      __syncthreads();
+      const int64_t ob = (int64_t)(bw0 + b) * 27 * AB;
+      if (out_ab) {
+        for (int j = rw; j < 27 * WT_T; j += 16) {     // row j = (tap, al), column = bl
+          const int tap = j >> 4, al = j & 15;
+          if (a0 + al < A && b0 + col < Bd)
+            wt_store(out_ab, dt_ab, ob + ((int64_t)tap * A + a0 + al) * Bd + b0 + col, tile[al * WT_PITCH + col * 27 + tap]);
+        }
+      }
+      if (out_ba) {
+        for (int j = rw; j < 27 * WT_T; j += 16) {     // row j = (tap, bl), column = al
+          const int tap = j >> 4, bl = j & 15;
+          if (a0 + col < A && b0 + bl < Bd)
+            wt_store(out_ba, dt_ba, ob + ((int64_t)tap * Bd + b0 + bl) * A + a0 + col, tile[col * WT_PITCH + bl * 27 + tap]);
+        }
+      }
+    }
+  }
+}
+
+// master [E][A][B][27] fp32 (+ r [Bw][E] or NULL)  ->  out_ab [Bw][27][A][B] and / or out_ba [Bw][27][B][A]
+extern "C" int coma_weight_prep_pair(const float* master, const float* r, int32_t E, int32_t Bw, int32_t A, int32_t B,
+                                     void* out_ab, int32_t dtype_ab, void* out_ba, int32_t dtype_ba, void* stream) {
+  COMA_CHECK(master && (out_ab || out_ba), "weight_prep_pair: null argument");
+  COMA_CHECK(E >= 1 && Bw >= 1 && (r || E == 1), "weight_prep_pair: E=%d needs routing weights", E);
+  COMA_CHECK((!out_ab || dtype_ab == COMA_F32 || dtype_ab == COMA_BF16) && (!out_ba || dtype_ba == COMA_F32 || dtype_ba == COMA_BF16),
+             "weight_prep_pair: unsupported output dtype");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((B + WT_T - 1) / WT_T), (unsigned)((A + WT_T - 1) / WT_T));
+  const int64_t se = (int64_t)A * B * 27;
+  for (int b0 = 0; b0 < Bw; b0 += 2) {
+    const int nb = Bw - b0 < 2 ? Bw - b0 : 2;
+    hipLaunchKernelGGL((weight_prep_tiled_k<2>), grid, dim3(256), 0, s, master, r, E, b0, nb, A, B, se, out_ab, dtype_ab, out_ba, dtype_ba);
+    COMA_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 // dmaster[e] (=) sum_b r[b][e] * dwk[b]  (master layout);  dr[b][e] (=) <dwk[b], master[e]>
 template <int TAPS, int BB>
 __global__ __launch_bounds__(256) void weight_prep_bwd_k(const float* dwk, const float* master, const float* r, int E, int Bw,

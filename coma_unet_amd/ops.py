@@ -131,13 +131,19 @@ def _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype):
     rr = r.contiguous().float() if has_e else None
     dev = master.device
     wk_f = _new((Bw, taps, cout, cin), fwd_dtype, dev)
-    check(lib.coma_weight_prep(ptr(m), ptr(rr), E, Bw, cout, cin, taps, se, sn_f, sc_f, ptr(wk_f),
-                               L.dtype_code(fwd_dtype), L.stream()), "coma_weight_prep")
-    wk_d = None
-    if dgrad_dtype is not None:
-        wk_d = _new((Bw, taps, cin, cout), dgrad_dtype, dev)
-        check(lib.coma_weight_prep(ptr(m), ptr(rr), E, Bw, cin, cout, taps, se, sc_f, sn_f, ptr(wk_d),
-                                   L.dtype_code(dgrad_dtype), L.stream()), "coma_weight_prep")
+    wk_d = _new((Bw, taps, cin, cout), dgrad_dtype, dev) if dgrad_dtype is not None else None
+    if taps == 27:
+        # one pass over the experts writes both layouts: [tap][A][B] and [tap][B][A] of master [E][A][B][27]
+        ab, ba = (wk_d, wk_f) if transposed else (wk_f, wk_d)
+        check(lib.coma_weight_prep_pair(ptr(m), ptr(rr), E, Bw, A, Bc, ptr(ab), L.dtype_code(ab.dtype) if ab is not None else 0,
+                                        ptr(ba), L.dtype_code(ba.dtype) if ba is not None else 0, L.stream()),
+              "coma_weight_prep_pair")
+    else:
+        check(lib.coma_weight_prep(ptr(m), ptr(rr), E, Bw, cout, cin, taps, se, sn_f, sc_f, ptr(wk_f),
+                                   L.dtype_code(fwd_dtype), L.stream()), "coma_weight_prep")
+        if wk_d is not None:
+            check(lib.coma_weight_prep(ptr(m), ptr(rr), E, Bw, cin, cout, taps, se, sc_f, sn_f, ptr(wk_d),
+                                       L.dtype_code(dgrad_dtype), L.stream()), "coma_weight_prep")
     return wk_f, wk_d, rr, (has_e, E, Bw, cout, cin, taps, se, sn_f, sc_f)
 
 

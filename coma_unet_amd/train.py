@@ -68,7 +68,18 @@ class GraphedTrainStep:
             for _ in range(max(warmup, 2)):      # builds the flat optimizer layout, sizes workspaces
                 train_step(model, criterion, optimizer, self.batch, reducer)
         torch.cuda.current_stream().wait_stream(side)
+        self._capture()
+
+    def _hyper(self):
+        g = self.optimizer.param_groups[0]
+        return (float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"]))
+
+    def _capture(self):
+        """(Re)capture.  The optimizer's hyper-parameters are kernel arguments frozen into the graph, so a change of
+        learning rate (ReduceLROnPlateau, attn_unet_data_parallel.py:737,921) triggers one re-capture on the next call."""
+        model, criterion, optimizer, reducer = self.model, self.criterion, self.optimizer, self.reducer
         torch.cuda.synchronize()
+        self._captured_hyper = self._hyper()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread may query events while this thread captures
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
@@ -78,6 +89,9 @@ class GraphedTrainStep:
                 optimizer.zero_grad()
                 self.losses, self.outputs = forward_loss(model, criterion, self.batch)
                 self.losses[0].backward()
+        if reducer is None:
+            # capture executes nothing: undo the host-side step count train_step's optimizer.step() just added
+            optimizer._flat_step -= 1
 
     def load(self, batch):
         for k, v in batch.items():
@@ -87,6 +101,8 @@ class GraphedTrainStep:
     def __call__(self, batch=None):
         if batch is not None:
             self.load(batch)
+        if self.reducer is None and self._hyper() != self._captured_hyper:
+            self._capture()
         self.graph.replay()
         if self.reducer is None:
             self.optimizer._flat_step += 1

@@ -86,6 +86,11 @@ const char* coma_last_error(void);
 int coma_weight_prep(const float* master, const float* r, int32_t E, int32_t Bw,
                      int32_t N, int32_t C, int32_t taps, int64_t se, int64_t sn, int64_t sc,
                      void* out, int32_t out_dtype, void* stream);
+/* 27-tap masters, both kernel layouts from one pass over the experts: master [E][A][B][27]
+ * -> out_ab [Bw][27][A][B] and/or out_ba [Bw][27][B][A] (either may be NULL), each fp32 or bf16. */
+int coma_weight_prep_pair(const float* master, const float* r, int32_t E, int32_t Bw, int32_t A,
+                          int32_t B, void* out_ab, int32_t dtype_ab, void* out_ba, int32_t dtype_ba,
+                          void* stream);
 /* dwk: fp32 [Bw][taps][N][C]  ->  dmaster (=, fp32, master layout), dr [Bw][E] (=, fp32) */
 int coma_weight_prep_bwd(const float* dwk, const float* master, const float* r, int32_t E,
                          int32_t Bw, int32_t N, int32_t C, int32_t taps, int64_t se,

@@ -298,3 +298,63 @@ def test_write_through_gradients_equal_autograd_accumulation():
     print("write-through vs accumulate, worst:", worst)
     assert worst[0] <= 1e-3, worst      # wgrad atomics order differs run to run
     assert nbt[0] == nbt[1] and any(v == 6 for v in nbt[0].values()) and any(v == 3 for v in nbt[0].values())
+
+
+def test_checkpoint_roundtrip_and_plateau_scheduler(tmp_path):
+    """ReduceLROnPlateau drives FusedAdamW (eager and graph-replayed: a learning-rate change re-captures),
+    and a checkpoint in the reference's format (attn_unet_data_parallel.py:943-955) restores model, moments, step count
+    and scheduler so that the resumed run takes the same next step."""
+    import coma_unet_amd as cu
+    from coma_unet_amd import checkpoint
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, make_optimizer, GraphedTrainStep
+    from torch.optim.lr_scheduler import ReduceLROnPlateau
+    S = (32, 32, 32)
+    b = make_batch(2, S, seed=41)
+
+    def fresh():
+        torch.manual_seed(6)
+        gm = cu.build_model(volume_shape=S, static_prompts=True).cuda()
+        gm.set_save_attn(None)
+        gm.train(True)
+        gb = _gpu_batch(b)
+        gb["roi_pred_dicts"] = gm._priors(b["roi_pred_dicts"], 2, torch.device("cuda"))
+        opt = make_optimizer(gm, 1e-3)
+        return gm, gb, opt, ReduceLROnPlateau(opt, "min", patience=0, factor=0.5)
+
+    gm, gb, opt, sched = fresh()
+    crit = cu.build_reference_criterion()
+    for _ in range(3):
+        loss = train_step(gm, crit, opt, gb)[0][0]
+    sched.step(1.0)
+    sched.step(2.0)                       # no improvement with patience 0 -> lr halves
+    assert abs(opt.param_groups[0]["lr"] - 5e-4) < 1e-12
+    files = checkpoint.save_checkpoint(str(tmp_path), 7, gm, opt, loss, sched, checkpoint_iter=7)
+    assert [os.path.basename(f) for f in files] == ["checkpoint_latest_epoch.pth", "checkpoint_epoch_7.pth"]
+    raw = torch.load(files[0], map_location="cpu", weights_only=True)
+    assert set(raw) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss", "scheduler_state_dict"}
+    assert set(raw["optimizer_state_dict"]) == {"state", "param_groups"} and raw["optimizer_state_dict"]["param_groups"][0]["lr"] == 5e-4
+    st0 = raw["optimizer_state_dict"]["state"][0]
+    assert set(st0) == {"step", "exp_avg", "exp_avg_sq"} and float(st0["step"]) == 3.0
+    next_loss = float(train_step(gm, crit, opt, gb)[0][0])            # step 4 of the original run (lr 5e-4)
+    after4 = {n: p.detach().clone() for n, p in gm.named_parameters()}
+
+    gm2, gb2, opt2, sched2 = fresh()
+    for _ in range(2):                     # the flat optimizer layout exists after the first steps; then restore
+        train_step(gm2, crit, opt2, gb2)
+    assert checkpoint.load_checkpoint(files[0], gm2, opt2, sched2) == 8
+    assert opt2.param_groups[0]["lr"] == 5e-4 and sched2.state_dict()["best"] == sched.state_dict()["best"]
+    l2 = float(train_step(gm2, crit, opt2, gb2)[0][0])
+    assert abs(l2 - next_loss) <= 1e-3 * abs(next_loss)
+    worst = max(rel(p, after4[n]) for n, p in gm2.named_parameters() if float(after4[n].abs().max()) > 0)
+    assert worst < 5e-3, worst             # same step from the same state (atomics order differs run to run)
+
+    # graph replay follows a scheduler change by re-capturing
+    gm3, gb3, opt3, sched3 = fresh()
+    g = GraphedTrainStep(gm3, crit, opt3, gb3, warmup=2)
+    g()
+    opt3.param_groups[0]["lr"] = 0.0       # a step with lr 0 must leave the parameters where they are
+    before = {n: p.detach().clone() for n, p in gm3.named_parameters()}
+    g()
+    assert g._captured_hyper[0] == 0.0
+    assert all(torch.equal(p, before[n]) for n, p in gm3.named_parameters())
