@@ -26,7 +26,8 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from . import ops
-from .layers import (Config, Convolution, MonaiConvBlock, CondConvolution, CondConvBlock, norm_act, conv_plain)
+from .layers import (Config, Convolution, MonaiConvBlock, CondConvolution, CondConvBlock, norm_act, conv_plain,
+                     conv_then_bn)
 from .ops import Out
 from .roi_tables import ROI_INDICES, ROI_NAMES, ROI_INDEX_TO_NAME
 
@@ -76,10 +77,10 @@ class ObservableAttentionBlock(nn.Module):
 
     def forward(self, g, x, out=None):
         cfg = self.cfg
-        g1 = norm_act(cfg, self.W_g[0](g), self.W_g[1], L.NORM_BATCH, L.ACT_NONE, None, self.training)
-        x1 = norm_act(cfg, self.W_x[0](x), self.W_x[1], L.NORM_BATCH, L.ACT_NONE, None, self.training)
+        g1 = conv_then_bn(cfg, g, self.W_g[0], self.W_g[1], L.ACT_NONE, self.training)
+        x1 = conv_then_bn(cfg, x, self.W_x[0], self.W_x[1], L.ACT_NONE, self.training)
         s = ops.AddRelu.apply(g1, x1)
-        psi = norm_act(cfg, self.psi[0](s), self.psi[1], L.NORM_BATCH, L.ACT_SIGMOID, None, self.training)
+        psi = conv_then_bn(cfg, s, self.psi[0], self.psi[1], L.ACT_SIGMOID, self.training)
         att = ops.GateMul.apply(x, psi, Out(out) if out is not None else None)
         if self.save_attn:
             return att, psi

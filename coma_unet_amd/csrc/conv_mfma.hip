@@ -686,6 +686,8 @@ struct PwP {
   const bf16_t* w; long wsb;
   const float* bias; int bsb;
   int st8;
+  double2* stats;      // optional fused {sum, sumsq} partials of the stored outputs, [chunk][G][N] (as conv_mfma_halo2_k)
+  int stats_inst;
 };
 
 template <int KS, int NT>   // KS = ceil(C / 16) K steps, NT = ceil(N / 32) row tiles
@@ -717,6 +719,13 @@ __global__ __launch_bounds__(256) void conv_mfma_pw_k(PwP p) {
         bv[j][g4][q] = (p.bias && nn < p.N) ? p.bias[b * p.bsb + nn] : 0.f;
       }
   }
+  float st_s[NT][4][4], st_q[NT][4][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { st_s[j][g4][q] = 0.f; st_q[j][g4][q] = 0.f; }
   const long mtiles = (p.V + 31) / 32;
   for (long mt = (long)blockIdx.x * 4 + wid; mt < mtiles; mt += (long)gridDim.x * 4) {
     const long v = mt * 32 + fr;
@@ -742,7 +751,11 @@ __global__ __launch_bounds__(256) void conv_mfma_pw_k(PwP p) {
         for (int g4 = 0; g4 < 4; ++g4) {
           bf16_t o[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = static_cast<bf16_t>(acc[g4 * 4 + q] + bv[j][g4][q]);
+          for (int q = 0; q < 4; ++q) {
+            o[q] = static_cast<bf16_t>(acc[g4 * 4 + q] + bv[j][g4][q]);
+            const float r = static_cast<float>(o[q]);
+            st_s[j][g4][q] += r; st_q[j][g4][q] = fmaf(r, r, st_q[j][g4][q]);
+          }
           if (p.st8 && j * 32 + 8 * g4 + 4 * fh + 3 < p.N) *reinterpret_cast<uint2*>(dst + 8 * g4) = *reinterpret_cast<uint2*>(o);
           else {
 #pragma unroll
@@ -750,6 +763,31 @@ __global__ __launch_bounds__(256) void conv_mfma_pw_k(PwP p) {
           }
         }
       }
+    }
+  }
+  // ---- fused statistics: lanes -> wave -> block -> partial[chunk] (same scheme as conv_mfma_halo2_k) ----
+  if (p.stats) {
+    __shared__ float red[4 * 64 * 2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float a = st_s[j][g4][q], c = st_q[j][g4][q];
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+          const int n = j * 32 + 8 * g4 + 4 * fh + q;
+          if (fr == 0) { red[(wid * 64 + n) * 2] = a; red[(wid * 64 + n) * 2 + 1] = c; }
+        }
+    __syncthreads();
+    if (tid < NT * 32 && tid < p.N) {
+      double a = 0.0, c = 0.0;
+      for (int w = 0; w < 4; ++w) { a += (double)red[(w * 64 + tid) * 2]; c += (double)red[(w * 64 + tid) * 2 + 1]; }
+      const int G = p.stats_inst ? gridDim.y : 1;
+      const int g = p.stats_inst ? b : 0;
+      const int chunk = p.stats_inst ? blockIdx.x : blockIdx.x + gridDim.x * b;
+      p.stats[((long)chunk * G + g) * p.N + tid] = make_double2(a, c);
     }
   }
 }
@@ -888,6 +926,13 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
     const int ks = (x->C + 15) / 16, nt = (y->C + 31) / 32;
     long nb = ((q.V + 31) / 32 + 3) / 4;
     if (nb > 2048) nb = 2048;
+    q.stats = nullptr; q.stats_inst = stats_inst;
+    if (stats) {                                   // the statistics workspace holds 1024 (chunk, group) partial rows
+      const long cap = 1024 / x->B;
+      if (nb > cap) nb = cap;
+      q.stats = stats;
+      *stats_chunks = stats_inst ? (int)nb : (int)nb * x->B;
+    }
     dim3 grid((unsigned)nb, (unsigned)x->B);
 #define PWL(K_, N_) hipLaunchKernelGGL((conv_mfma_pw_k<K_, N_>), grid, dim3(256), 0, s, q)
     if (nt == 1) { if (ks == 1) PWL(1, 1); else if (ks == 2) PWL(2, 1); else if (ks == 3) PWL(3, 1); else PWL(4, 1); }

@@ -108,6 +108,17 @@ def conv_norm_act(cfg, x, conv_fn, adn, out=None):
     return norm_act(cfg, y, bn, adn.mode, _ACTS[adn.act_name], slope, adn.training, out, pre=(mean, rstd))
 
 
+def conv_then_bn(cfg, x, cv, bn, act, training, out=None):
+    """``nn.Sequential(Convolution(conv_only=True), BatchNorm3d[, act])`` (the attention gate's W_g / W_x / psi,
+    attn_unet_data_parallel.py:104-137 via MONAI AttentionBlock): the batch statistics come out of the convolution pass
+    and the convolution's bias -- removed again by the BatchNorm -- gets its exact zero gradient."""
+    if not training:
+        return norm_act(cfg, cv(x), bn, L.NORM_BATCH, act, None, False, out)
+    _g, _b, rmean, rvar, momentum, eps = _norm_params(cfg, bn, True)
+    y, mean, rstd = conv_plain(cfg, x, cv.conv, cv.k, cv.s, cv.transposed, None, (L.NORM_BATCH, eps, rmean, rvar, momentum))
+    return norm_act(cfg, y, bn, L.NORM_BATCH, act, None, True, out, pre=(mean, rstd))
+
+
 def conv_plain(cfg, x, conv: nn.Module, ksize, stride, transposed, out=None, norm=None):
     """nn.Conv3d / nn.ConvTranspose3d semantics with shared weights."""
     n_out = conv.weight.shape[1] if transposed else conv.weight.shape[0]
