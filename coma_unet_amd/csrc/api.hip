@@ -19,6 +19,11 @@ int conv_check(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor*
 int conv_direct_fwd(const coma_conv_desc* d, const coma_tensor* x, const float* wk, const float* bias,
                     const coma_tensor* y, hipStream_t s);
 int conv_direct_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s);
+// conv_point1.hip
+bool conv_point1_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
+int conv_point1_fwd(const coma_conv_desc* d, const coma_tensor* x, const float* wk, const float* bias, const coma_tensor* y,
+                    hipStream_t s);
+int conv_point1_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s);
 // norm.hip
 int colsum(const coma_tensor* x, int per_sample, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 // conv_mfma.hip
@@ -52,11 +57,12 @@ extern "C" int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, cons
     return conv_mfma_fwd(d, x, wk, bias, y, s);
   }
   COMA_CHECK(wk_dtype == COMA_F32, "conv_fwd: direct path needs fp32 kernel-layout weights");
+  if (conv_point1_ok(d, x, y)) return conv_point1_fwd(d, x, (const float*)wk, bias, y, s);
   return conv_direct_fwd(d, x, (const float*)wk, bias, y, s);
 }
 
 extern "C" int coma_conv_wgrad_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
-  if (d->algo == 1) return 1;
+  if (d->algo == 1 || conv_point1_ok(d, x, dy)) return 1;
   return (x->dtype == COMA_BF16 && conv_mfma_wgrad_supported(d, x, dy)) ? 2 : 1;
 }
 
@@ -100,6 +106,7 @@ extern "C" int coma_conv_wgrad(const coma_conv_desc* d, const coma_tensor* x, co
     COMA_CHECK(ws && ws_bytes >= coma_norm_ws_bytes(dy), "conv_wgrad: workspace too small for the bias gradient");
     if (int rc = colsum(dy, d->per_sample_w, dbias, ws, ws_bytes, s)) return rc;
   }
+  if (conv_point1_ok(d, x, dy)) return conv_point1_wgrad(d, x, dy, dwk, s);
   const int algo = coma_conv_wgrad_algo(d, x, dy);
   if (algo == 2) {
     COMA_CHECK(conv_mfma_wgrad_supported(d, x, dy), "conv_wgrad: shape not supported by the MFMA path");

@@ -37,6 +37,7 @@ CONV_CASES = [
     (64, 32, 3, 1, False, 6), (32, 16, 1, 1, False, 6), (16, 1, 1, 1, False, 6), (3, 16, 3, 1, False, 7),
     (16, 1, 3, 1, False, 6), (2, 8, 3, 1, False, 5), (8, 8, 3, 1, False, 5), (2, 1, 1, 1, False, 5),
     (128, 64, 3, 2, True, 3), (64, 128, 3, 2, False, 6), (5, 7, 3, 2, False, 9), (7, 5, 3, 2, True, 5),
+    (32, 1, 1, 1, False, 6), (1, 1, 1, 1, False, 5), (128, 1, 1, 1, False, 4), (24, 1, 1, 1, False, 5),
 ]
 
 
