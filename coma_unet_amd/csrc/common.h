@@ -49,6 +49,20 @@ template <> struct vec_io<bf16_t, 4> {
     bf16_t t[4] = {static_cast<bf16_t>(o[0]), static_cast<bf16_t>(o[1]), static_cast<bf16_t>(o[2]), static_cast<bf16_t>(o[3])};
     *reinterpret_cast<uint2*>(p) = *reinterpret_cast<uint2*>(t); }
 };
+template <> struct vec_io<bf16_t, 8> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(u[j] << 16); o[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float* o) {
+    bf16_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = static_cast<bf16_t>(o[j]);
+    *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(t);
+  }
+};
 template <typename T> struct vec_io<T, 1> {
   static __device__ __forceinline__ void load(const T* p, float* o) { o[0] = ld_f(p); }
   static __device__ __forceinline__ void store(T* p, const float* o) { st_f(p, o[0]); }

@@ -117,7 +117,28 @@ __global__ __launch_bounds__(256) void norm_act_fwd_k(ApplyP p) {
   const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.sbx;
   T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * p.sby;
   const int g = p.inst ? b : 0;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256, e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (stride % p.cv == 0) {
+    // the thread keeps its channel group for the whole sweep: scale / shift live in registers, no division in the loop
+    const int c0 = (int)(e0 % p.cv) * VEC;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float rs = p.rstd[g * p.C + c0 + j], ga = p.gamma ? p.gamma[c0 + j] : 1.f;
+      sc[j] = rs * ga;
+      sh[j] = (p.gamma ? p.beta[c0 + j] : 0.f) - p.mean[g * p.C + c0 + j] * rs * ga;
+    }
+    const int64_t dv = stride / p.cv;
+    for (int64_t v = e0 / p.cv; v < p.V; v += dv) {
+      float xv[VEC], yv[VEC];
+      vec_io<T, VEC>::load(xb + v * p.ldx + c0, xv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) yv[j] = act_fwd(p.act, fmaf(xv[j], sc[j], sh[j]), a);
+      vec_io<T, VEC>::store(yb + v * p.ldy + c0, yv);
+    }
+    return;
+  }
+  for (int64_t e = e0; e < total; e += stride) {
     const int64_t v = e / p.cv; const int c0 = (int)(e - v * p.cv) * VEC;
     float xv[VEC], yv[VEC];
     vec_io<T, VEC>::load(xb + v * p.ldx + c0, xv);
@@ -233,7 +254,35 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p, const floa
   const T* dyb = reinterpret_cast<const T*>(p.dy) + (int64_t)b * p.sbdy;
   T* ob = reinterpret_cast<T*>(p.y) + (int64_t)b * p.sby;
   const int g = p.inst ? b : 0;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256, e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (stride % p.cv == 0) {      // fixed channel group per thread: the per-channel constants live in registers
+    const int c0 = (int)(e0 % p.cv) * VEC;
+    float rs[VEC], mu[VEC], ga[VEC], be[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      rs[j] = p.rstd[g * p.C + c]; mu[j] = p.mean[g * p.C + c];
+      ga[j] = p.gamma ? p.gamma[c] : 1.f; be[j] = p.gamma ? p.beta[c] : 0.f;
+      s1[j] = sums[(g * p.C + c) * 2]; s2[j] = sums[(g * p.C + c) * 2 + 1];
+    }
+    const int64_t dvx = stride / p.cv;
+    for (int64_t v = e0 / p.cv; v < p.V; v += dvx) {
+      float xv[VEC], dv[VEC], ov[VEC];
+      vec_io<T, VEC>::load(xb + v * p.ldx + c0, xv);
+      vec_io<T, VEC>::load(dyb + v * p.lddy + c0, dv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float xh = (xv[j] - mu[j]) * rs[j];
+        const float z = p.gamma ? xh * ga[j] + be[j] : xh;
+        float ds; const float da = act_bwd(p.act, z, a, &ds);
+        const float dz = dv[j] * da;
+        ov[j] = rs[j] * ga[j] * (dz - s1[j] - xh * s2[j]);
+      }
+      vec_io<T, VEC>::store(ob + v * p.ldy + c0, ov);
+    }
+    return;
+  }
+  for (int64_t e = e0; e < total; e += stride) {
     const int64_t v = e / p.cv; const int c0 = (int)(e - v * p.cv) * VEC;
     float xv[VEC], dv[VEC], ov[VEC];
     vec_io<T, VEC>::load(xb + v * p.ldx + c0, xv);
@@ -355,13 +404,14 @@ extern "C" int coma_norm_act_fwd(const coma_tensor* x, int32_t mode, const float
   hipStream_t s = (hipStream_t)stream;
   COMA_CHECK(x && y && x->data && y->data && mean && rstd, "norm_act_fwd: null argument");
   COMA_CHECK(t_same_grid(x, y) && x->C == y->C && x->dtype == y->dtype, "norm_act_fwd: shape/dtype mismatch");
-  const int vec = (pick_vec(x) == 4 && pick_vec(y) == 4) ? 4 : 1;
+  int vec = (pick_vec(x) == 4 && pick_vec(y) == 4) ? 4 : 1;
+  if (x->dtype == COMA_BF16 && t_vec(x, 8) == 8 && t_vec(y, 8) == 8) vec = 8;     // 16 bytes per lane
   ApplyP p = make_apply(x, y, mode, vec);
   p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.slope = slope; p.act = act;
   dim3 grid(ew_blocks(p.V * p.cv), x->B);
 #define L(T, V) hipLaunchKernelGGL((norm_act_fwd_k<T, V>), grid, dim3(256), 0, s, p)
   if (x->dtype == COMA_F32) { if (vec == 4) L(float, 4); else L(float, 1); }
-  else { if (vec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
+  else { if (vec == 8) L(bf16_t, 8); else if (vec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
 #undef L
   COMA_LAUNCH_CHECK();
   return 0;
@@ -396,13 +446,15 @@ extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, in
     hipLaunchKernelGGL(norm_bwd_finalize_k, dim3(1), dim3(256), 0, s, tot, rp.G, rp.C, dgamma, dbeta, dslope);
     COMA_LAUNCH_CHECK();
   }
-  ApplyP p = make_apply(x, dx, mode, vec);
+  int avec = vec;
+  if (x->dtype == COMA_BF16 && t_vec(x, 8) == 8 && t_vec(dy, 8) == 8 && t_vec(dx, 8) == 8) avec = 8;
+  ApplyP p = make_apply(x, dx, mode, avec);
   p.dy = dy->data; p.lddy = dy->ld; p.sbdy = dy->sb;
   p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.slope = slope; p.act = act;
   dim3 grid(ew_blocks(p.V * p.cv), x->B);
 #define L(T, V) hipLaunchKernelGGL((norm_act_bwd_apply_k<T, V>), grid, dim3(256), 0, s, p, sums)
-  if (x->dtype == COMA_F32) { if (vec == 4) L(float, 4); else L(float, 1); }
-  else { if (vec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
+  if (x->dtype == COMA_F32) { if (avec == 4) L(float, 4); else L(float, 1); }
+  else { if (avec == 8) L(bf16_t, 8); else if (avec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
 #undef L
   COMA_LAUNCH_CHECK();
   return 0;
