@@ -40,6 +40,21 @@ __device__ __forceinline__ int64_t row_off(const RowsP& p, int g, int64_t r) {
   return (int64_t)g * p.sb + r * p.ld;
 }
 
+// Rows r0 + ty, + ry, ... of group g without a 64-bit division per row: (sample, voxel) advance incrementally.
+struct RowWalk {
+  int64_t r, b, v;
+  __device__ __forceinline__ RowWalk(const RowsP& p, int64_t r_) : r(r_) {
+    if (p.G == 1) { b = r_ / p.V; v = r_ - b * p.V; } else { b = 0; v = r_; }
+  }
+  __device__ __forceinline__ int64_t off(const RowsP& p, int g, int64_t ld, int64_t sb) const {
+    return p.G == 1 ? b * sb + v * ld : (int64_t)g * sb + v * ld;
+  }
+  __device__ __forceinline__ void step(const RowsP& p) {
+    r += p.ry; v += p.ry;
+    if (p.G == 1 && v >= p.V) { v -= p.V; ++b; }      // ry <= 256 << V
+  }
+};
+
 // partial[(chunk*G + g)*C + c] = {sum, sumsq} over the chunk's rows
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double2* partial) {
@@ -53,11 +68,27 @@ __global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double2* partial
   for (int j = 0; j < VEC; ++j) { s[j] = 0.0; q[j] = 0.0; }
   if (tx < p.cv) {
     const T* base = reinterpret_cast<const T*>(p.x);
-    for (int64_t r = r0 + ty; r < r1; r += p.ry) {
-      float v[VEC];
-      vec_io<T, VEC>::load(base + row_off(p, g, r) + tx * VEC, v);
+    // bf16 volumes: fp32 sums over bursts of 8 rows, folded into the fp64 accumulators (an 8-term fp32 sum of
+    // bf16-sized data loses nothing that matters; the long reduction stays fp64).  fp32 volumes: every term goes
+    // straight to fp64 (burst of 1), as the exact-fp32 mode's gradient parity needs.
+    constexpr int BURST = sizeof(T) == 2 ? 8 : 1;
+    RowWalk w(p, r0 + ty);
+    while (w.r < r1) {
+      float fs[VEC], fq[VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { s[j] += (double)v[j]; q[j] += (double)v[j] * (double)v[j]; }
+      for (int j = 0; j < VEC; ++j) { fs[j] = 0.f; fq[j] = 0.f; }
+#pragma unroll
+      for (int u = 0; u < BURST; ++u) {
+        if (w.r < r1) {
+          float v[VEC];
+          vec_io<T, VEC>::load(base + w.off(p, g, p.ld, p.sb) + tx * VEC, v);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { fs[j] += v[j]; fq[j] = fmaf(v[j], v[j], fq[j]); }
+          w.step(p);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s[j] += (double)fs[j]; q[j] += (double)fq[j]; }
     }
   }
 #pragma unroll
@@ -171,7 +202,6 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
   if (tx < p.cv) {
     const T* xb = reinterpret_cast<const T*>(p.x);
     const T* dyb = reinterpret_cast<const T*>(dyp);
-    RowsP pd = p; pd.ld = lddy; pd.sb = sbdy;
     float mu[VEC], rs[VEC], ga[VEC], be[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -179,18 +209,31 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
       mu[j] = mean[g * p.C + c]; rs[j] = rstd[g * p.C + c];
       ga[j] = gamma ? gamma[c] : 1.f; be[j] = gamma ? beta[c] : 0.f;
     }
-    for (int64_t r = r0 + ty; r < r1; r += p.ry) {
-      float xv[VEC], dv[VEC];
-      vec_io<T, VEC>::load(xb + row_off(p, g, r) + tx * VEC, xv);
-      vec_io<T, VEC>::load(dyb + row_off(pd, g, r) + tx * VEC, dv);
+    constexpr int BURST = sizeof(T) == 2 ? 8 : 1;
+    RowWalk w(p, r0 + ty);
+    while (w.r < r1) {             // bf16: fp32 bursts of 8 rows folded into fp64 (see stats_partial_k)
+      float f1[VEC], f2[VEC], f3[VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const float xh = (xv[j] - mu[j]) * rs[j];
-        const float z = xh * ga[j] + be[j];
-        float ds; const float da = act_bwd(act, z, a, &ds);
-        const float dz = dv[j] * da;
-        s1[j] += (double)dz; s2[j] += (double)dz * (double)xh; s3[j] += (double)dv[j] * (double)ds;
+      for (int j = 0; j < VEC; ++j) { f1[j] = 0.f; f2[j] = 0.f; f3[j] = 0.f; }
+#pragma unroll
+      for (int u = 0; u < BURST; ++u) {
+        if (w.r < r1) {
+          float xv[VEC], dv[VEC];
+          vec_io<T, VEC>::load(xb + w.off(p, g, p.ld, p.sb) + tx * VEC, xv);
+          vec_io<T, VEC>::load(dyb + w.off(p, g, lddy, sbdy) + tx * VEC, dv);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float xh = (xv[j] - mu[j]) * rs[j];
+            const float z = xh * ga[j] + be[j];
+            float ds; const float da = act_bwd(act, z, a, &ds);
+            const float dz = dv[j] * da;
+            f1[j] += dz; f2[j] = fmaf(dz, xh, f2[j]); f3[j] = fmaf(dv[j], ds, f3[j]);
+          }
+          w.step(p);
+        }
       }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s1[j] += (double)f1[j]; s2[j] += (double)f2[j]; s3[j] += (double)f3[j]; }
     }
   }
 #pragma unroll
@@ -314,6 +357,8 @@ __global__ __launch_bounds__(256) void colsum_finalize_k(const double2* partial,
 }
 
 static int pick_vec(const coma_tensor* x) { return t_vec(x, 4) >= 4 ? 4 : 1; }
+// 16 bytes per lane where the layout allows (bf16 volumes with C, pitch, base multiples of 8 channels)
+static int pick_vec8(const coma_tensor* x) { return (x->dtype == COMA_BF16 && t_vec(x, 8) == 8) ? 8 : pick_vec(x); }
 
 extern "C" size_t coma_norm_ws_bytes(const coma_tensor* x) {
   // partials: <= 1024 (chunk,group) pairs x C x 3 doubles, + sums [B][C][2] floats
@@ -323,14 +368,15 @@ extern "C" size_t coma_norm_ws_bytes(const coma_tensor* x) {
 template <typename T>
 static void launch_partial(const RowsP& p, int vec, double2* partial, hipStream_t s) {
   dim3 grid(p.nchunks, p.G);
-  if (vec == 4) hipLaunchKernelGGL((stats_partial_k<T, 4>), grid, dim3(256), 0, s, p, partial);
+  if (vec == 8) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((stats_partial_k<T, 8>), grid, dim3(256), 0, s, p, partial); }
+  else if (vec == 4) hipLaunchKernelGGL((stats_partial_k<T, 4>), grid, dim3(256), 0, s, p, partial);
   else hipLaunchKernelGGL((stats_partial_k<T, 1>), grid, dim3(256), 0, s, p, partial);
 }
 
 static int run_partial(const coma_tensor* x, int mode, RowsP& p, void* ws, size_t ws_bytes, hipStream_t s) {
   COMA_CHECK(x && x->data && ws, "norm: null argument");
   COMA_CHECK(ws_bytes >= coma_norm_ws_bytes(x), "norm: workspace too small (%zu < %zu)", ws_bytes, coma_norm_ws_bytes(x));
-  const int vec = pick_vec(x);
+  const int vec = pick_vec8(x);
   p = make_rows(x, mode, vec);
   COMA_CHECK(p.cv <= 256, "norm: C=%d too large", x->C);
   if (x->dtype == COMA_F32) launch_partial<float>(p, vec, (double2*)ws, s);
@@ -427,7 +473,8 @@ extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, in
   COMA_CHECK(x->dtype == dy->dtype && x->dtype == dx->dtype, "norm_act_bwd: dtype mismatch");
   COMA_CHECK(ws_bytes >= coma_norm_ws_bytes(x), "norm_act_bwd: workspace too small");
   const int vec = (pick_vec(x) == 4 && pick_vec(dy) == 4 && pick_vec(dx) == 4) ? 4 : 1;
-  RowsP rp = make_rows(x, mode, vec);
+  const int pvec = vec;     // (8-wide measured slower here: 24 fp64 accumulators per lane, 48 KB of LDS)
+  RowsP rp = make_rows(x, mode, pvec);
   COMA_CHECK(rp.cv <= 256, "norm: C=%d too large", x->C);
   double* partial = (double*)ws;
   double* tot = (double*)((char*)ws + (size_t)1024 * x->C * 3 * sizeof(double));
@@ -435,8 +482,8 @@ extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, in
   dim3 pg(rp.nchunks, rp.G);
 #define L(T, V) hipLaunchKernelGGL((norm_bwd_partial_k<T, V>), pg, dim3(256), 0, s, rp, dy->data, dy->ld, dy->sb, \
                                    mean, rstd, gamma, beta, act, slope, partial)
-  if (x->dtype == COMA_F32) { if (vec == 4) L(float, 4); else L(float, 1); }
-  else { if (vec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
+  if (x->dtype == COMA_F32) { if (pvec == 4) L(float, 4); else L(float, 1); }
+  else { if (pvec == 8) L(bf16_t, 8); else if (pvec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
 #undef L
   COMA_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_bwd_reduce_k, dim3((rp.G * rp.C + 3) / 4), dim3(256), 0, s, partial, rp.nchunks, rp.G, rp.C,
