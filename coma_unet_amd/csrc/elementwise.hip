@@ -402,21 +402,30 @@ extern "C" int coma_l1_bwd(const coma_tensor* pred, const coma_tensor* gt, const
 // ---- AdamW (torch.optim.AdamW: decoupled decay, bias-corrected, eps outside sqrt(v_hat)) ----
 __global__ __launch_bounds__(256) void adamw_k(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                                                float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                               const int32_t* step_dev) {
+                                               const int32_t* step_dev, int vec4) {
   if (step_dev) {   // step count lives on the device (hipGraph replays must not freeze it)
     const float st = (float)*step_dev;
     bc1 = 1.f - powf(b1, st);
     bc2_sqrt = sqrtf(1.f - powf(b2, st));
   }
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i];
-    float pi = p[i] * (1.f - lr * wd);
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
+  auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+    pi *= (1.f - lr * wd);
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     pi -= (lr / bc1) * (mi / denom);
-    p[i] = pi;
+  };
+  const int64_t n4 = vec4 ? n >> 2 : 0;        // 16 bytes per lane and stream where the four buffers are 16-byte aligned
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    upd(pv.x, gv.x, mv.x, vv.x); upd(pv.y, gv.y, mv.y, vv.y); upd(pv.z, gv.z, mv.z, vv.z); upd(pv.w, gv.w, mv.w, vv.w);
+    reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    upd(pi, g[i], mi, vi);
+    p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
 extern "C" int coma_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
@@ -425,8 +434,9 @@ extern "C" int coma_adamw(float* p, const float* g, float* m, float* v, int64_t 
   if (n == 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adamw_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, sqrtf(bc2), step_dev);
+  const int vec4 = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+  hipLaunchKernelGGL(adamw_k, dim3(ew_grid(vec4 ? (n + 3) / 4 : n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, bc1, sqrtf(bc2), step_dev, vec4);
   COMA_LAUNCH_CHECK();
   return 0;
 }
