@@ -112,3 +112,22 @@ __device__ __forceinline__ float act_bwd(int act, float z, float a, float* dslop
     default: return 1.f;
   }
 }
+
+// ROI label -> slot lookup shared by the loss / painting / evaluation kernels.  Labels are floats holding integer
+// atlas ids (17..2035 for the 36 ROIs): a 4096-entry table in LDS replaces a 36-way linear search per voxel.
+#define COMA_ROI_LUT 4096
+__device__ __forceinline__ void roi_lut_build(signed char* lut, const int32_t* ids, int n) {   // whole block calls this
+  for (int i = threadIdx.x; i < COMA_ROI_LUT; i += blockDim.x) lut[i] = -1;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int i = n - 1; i >= 0; --i)             // reverse: the first occurrence of a duplicated id wins, as a search would
+      if ((unsigned)ids[i] < COMA_ROI_LUT) lut[ids[i]] = (signed char)i;
+  __syncthreads();
+}
+__device__ __forceinline__ int roi_lut_slot(const signed char* lut, const int32_t* ids, int n, float label) {
+  const int li = (int)label;
+  if ((float)li != label) return -1;
+  if ((unsigned)li < COMA_ROI_LUT) return lut[li];
+  for (int i = 0; i < n; ++i) if (ids[i] == li) return i;
+  return -1;
+}

@@ -225,6 +225,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void roi_paint_fwd_k(RoiP p) {
   __shared__ int32_t ids[64];
   __shared__ float pri[128];
+  __shared__ signed char lut[COMA_ROI_LUT];
   const int b = blockIdx.y;
   if (threadIdx.x < p.n_roi) {
     ids[threadIdx.x] = p.ids[threadIdx.x];
@@ -232,13 +233,14 @@ __global__ __launch_bounds__(256) void roi_paint_fwd_k(RoiP p) {
     pri[2 * threadIdx.x + 1] = p.prior[((int64_t)b * p.n_roi + threadIdx.x) * 2 + 1];
   }
   __syncthreads();
+  roi_lut_build(lut, ids, p.n_roi);
   const float* prompt = p.abeta[b] == 1.f ? p.pos : p.neg;   // attn_unet_data_parallel.py:638-639
   const float* rb = p.roi + (int64_t)b * p.sbr;
   const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.sbx;
   T* ob = reinterpret_cast<T*>(p.out) + (int64_t)b * p.sbo;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < p.V; v += (int64_t)gridDim.x * 256) {
     float suvr = 0.f, sal = 0.f;
-    const int slot = roi_slot(ids, p.n_roi, rb[v]);
+    const int slot = roi_lut_slot(lut, ids, p.n_roi, rb[v]);
     if (slot >= 0 && !(ld_f(xb + v * p.ldx) < 1e-4f)) { suvr = pri[2 * slot]; sal = pri[2 * slot + 1]; }
     T* o = ob + v * p.ldo;
     st_f(o, prompt[v]); st_f(o + 1, sal); st_f(o + 2, suvr);   // cat((prompt, saliency, suvr)) :651
@@ -299,14 +301,16 @@ __global__ __launch_bounds__(256) void loss_partial_k(const T* pred, int64_t sbp
   __shared__ int32_t ids[64];
   __shared__ float w[64];
   __shared__ double sh[256][2];
+  __shared__ signed char lut[COMA_ROI_LUT];
   const int b = blockIdx.y;
   if (roi && threadIdx.x < n_roi) { ids[threadIdx.x] = ids_g[threadIdx.x]; w[threadIdx.x] = w_g[threadIdx.x]; }
   __syncthreads();
+  if (roi) roi_lut_build(lut, ids, n_roi);
   double sm = 0.0, se = 0.0;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
     const float d = ld_f(pred + b * sbp + v * ldp) - ld_f(gt + b * sbg + v);
     se += L1 ? (double)fabsf(d) : (double)d * (double)d;
-    if (roi) { const int slot = roi_slot(ids, n_roi, roi[b * sbr + v]); if (slot >= 0) sm += (double)w[slot]; }
+    if (roi) { const int slot = roi_lut_slot(lut, ids, n_roi, roi[b * sbr + v]); if (slot >= 0) sm += (double)w[slot]; }
   }
   sh[threadIdx.x][0] = sm; sh[threadIdx.x][1] = se;
   __syncthreads();
@@ -317,10 +321,11 @@ __global__ __launch_bounds__(256) void loss_partial_k(const T* pred, int64_t sbp
   if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = make_double2(sh[0][0], sh[0][1]);
 }
 __global__ void loss_finalize_k(const double2* partial, int nblk, int B, int64_t V, float* loss, float* mask_mean, int l1) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int b = blockIdx.x, lane = threadIdx.x;     // one 64-lane wave per sample, fixed-order butterfly
   double sm = 0.0, se = 0.0;
-  for (int k = 0; k < nblk; ++k) { sm += partial[(int64_t)b * nblk + k].x; se += partial[(int64_t)b * nblk + k].y; }
+  for (int k = lane; k < nblk; k += 64) { sm += partial[(int64_t)b * nblk + k].x; se += partial[(int64_t)b * nblk + k].y; }
+  for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); se += __shfl_xor(se, o, 64); }
+  if (lane != 0) return;
   const double mm = sm / (double)V, ms = se / (double)V;
   if (l1) { loss[b] = (float)ms; }
   else { loss[b] = (float)(mm * ms); mask_mean[b] = (float)mm; }
@@ -350,7 +355,7 @@ static int loss_fwd(const coma_tensor* pred, const coma_tensor* gt, const coma_t
   else { if (l1) L(bf16_t, 1); else L(bf16_t, 0); }
 #undef L
   COMA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_finalize_k, dim3((pred->B + 63) / 64), dim3(64), 0, s, (const double2*)ws, nblk, pred->B, V,
+  hipLaunchKernelGGL(loss_finalize_k, dim3(pred->B), dim3(64), 0, s, (const double2*)ws, nblk, pred->B, V,
                      loss, mask_mean, l1);
   COMA_LAUNCH_CHECK();
   return 0;

@@ -15,8 +15,11 @@ __global__ __launch_bounds__(256) void eval_stats_k(const T* pred, int64_t sbp, 
                                                     int64_t sbr, const int32_t* ids_g, int n_roi, int64_t V, double* stats) {
   __shared__ int32_t ids[64];
   __shared__ double bins[64][EV_K];
+  __shared__ signed char lut[COMA_ROI_LUT];
   const int b = blockIdx.y;
   if (threadIdx.x < n_roi) ids[threadIdx.x] = ids_g[threadIdx.x];
+  __syncthreads();
+  roi_lut_build(lut, ids, n_roi);
   for (int i = threadIdx.x; i < 64 * EV_K; i += 256) (&bins[0][0])[i] = 0.0;
   __syncthreads();
   double g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0;   // whole-volume bin in registers
@@ -27,9 +30,7 @@ __global__ __launch_bounds__(256) void eval_stats_k(const T* pred, int64_t sbp, 
     g0 += 1.0; g1 += ad; g2 += (double)d * d; g3 += g; g4 += (double)g * g; g5 += p;
     if (fabsf(g) > 1e-8f) { g6 += (double)fabsf((g - p) / g); g7 += 1.0; }
     const float lab = roi[b * sbr + v];
-    const int li = (int)lab;
-    int slot = -1;
-    if ((float)li == lab) for (int i = 0; i < n_roi; ++i) if (ids[i] == li) { slot = i; break; }
+    const int slot = roi_lut_slot(lut, ids, n_roi, lab);
     if (slot >= 0) {
       double* bn = bins[slot];
       atomicAdd(bn + 0, 1.0); atomicAdd(bn + 1, (double)ad); atomicAdd(bn + 2, (double)d * d);
