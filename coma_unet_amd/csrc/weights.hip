@@ -158,7 +158,9 @@ template <int TAPS, int BB>
 __global__ __launch_bounds__(256) void weight_prep_bwd_k(const float* dwk, const float* master, const float* r, int E, int Bw,
                                                          int N, int C, int64_t se, int64_t sn, int64_t sc, float* dmaster,
                                                          float* dr) {
-  __shared__ float red[256];
+  __shared__ float red[64];          // [b][e] block totals of the dr dot products (Bw * E <= 64)
+  if (threadIdx.x < 64) red[threadIdx.x] = 0.f;
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = i < (int64_t)N * C;
   const int n = live ? (int)(i / C) : 0, c = live ? (int)(i - (int64_t)n * C) : 0;
@@ -183,12 +185,9 @@ __global__ __launch_bounds__(256) void weight_prep_bwd_k(const float* dwk, const
         float dot = 0.f;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) { dm[t] = fmaf(rb, g[b][t], dm[t]); dot = fmaf(g[b][t], w[t], dot); }
-        if (dr) {
-          red[threadIdx.x] = dot;
-          __syncthreads();
-          for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-          if (threadIdx.x == 0) atomicAdd(dr + b * E + e, red[0]);
-          __syncthreads();
+        if (dr) {       // wave butterfly, one LDS atomic per wave: no block barrier inside the expert loop
+          for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+          if ((threadIdx.x & 63) == 0) atomicAdd(&red[b * E + e], dot);
         }
       }
     }
@@ -197,6 +196,10 @@ __global__ __launch_bounds__(256) void weight_prep_bwd_k(const float* dwk, const
       for (int t = 0; t < TAPS; ++t) dmaster[off + t] = dm[t];
     }
   }
+  if (dr) {
+    __syncthreads();
+    if (threadIdx.x < Bw * E) atomicAdd(dr + threadIdx.x, red[threadIdx.x]);
+  }
 }
 
 extern "C" int coma_weight_prep_bwd(const float* dwk, const float* master, const float* r, int32_t E, int32_t Bw, int32_t N,
@@ -204,7 +207,7 @@ extern "C" int coma_weight_prep_bwd(const float* dwk, const float* master, const
                                     void* stream) {
   COMA_CHECK(dwk && master && dmaster, "weight_prep_bwd: null argument");
   COMA_CHECK(taps == 27 || taps == 1, "weight_prep_bwd: taps=%d unsupported", taps);
-  COMA_CHECK(Bw >= 1 && Bw <= 8, "weight_prep_bwd: Bw=%d out of range (1..8)", Bw);
+  COMA_CHECK(Bw >= 1 && Bw <= 8 && (!dr || Bw * E <= 64), "weight_prep_bwd: Bw=%d E=%d out of range (Bw 1..8, Bw*E <= 64)", Bw, E);
   hipStream_t s = (hipStream_t)stream;
   if (dr && hipMemsetAsync(dr, 0, sizeof(float) * Bw * E, s) != hipSuccess) { coma_set_error("weight_prep_bwd: memset failed"); return 2; }
   dim3 grid((unsigned)(((int64_t)N * C + 255) / 256));
