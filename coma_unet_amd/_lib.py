@@ -43,6 +43,8 @@ SIGNATURES = {
     "coma_routing_bwd": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "coma_conv_pick_algo": (_i32, [_DP, _TP, _TP]),
     "coma_conv_fwd": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _vp]),
+    "coma_conv_fwd_ws_bytes": (_sz, [_DP, _TP, _TP]),
+    "coma_conv_fwd_ws": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _vp, _sz, _vp]),
     "coma_conv_fwd_norm_stats": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _i32, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),
     "coma_conv_wgrad_algo": (_i32, [_DP, _TP, _TP]),
     "coma_conv_wgrad_ws_bytes": (_sz, [_DP, _TP, _TP]),

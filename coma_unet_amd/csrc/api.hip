@@ -30,7 +30,8 @@ int colsum(const coma_tensor* x, int per_sample, float* out, void* ws, size_t ws
 bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                   const coma_tensor* y, hipStream_t s, double2* stats = nullptr, int stats_inst = 0,
-                  int* stats_chunks = nullptr);
+                  int* stats_chunks = nullptr, void* ws = nullptr, size_t ws_bytes = 0);
+size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 // norm.hip
 int norm_stats_finalize(const double2* partial, int nchunks, int G, int C, int64_t R, float eps, float* mean, float* rstd,
                         float* running_mean, float* running_var, float momentum, hipStream_t s);
@@ -44,8 +45,17 @@ extern "C" int coma_conv_pick_algo(const coma_conv_desc* d, const coma_tensor* x
   return conv_mfma_supported(d, x, y) ? 2 : 1;   // algo 2 = "MFMA wherever the shape allows"
 }
 
+extern "C" size_t coma_conv_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  return coma_conv_pick_algo(d, x, y) == 2 ? conv_mfma_fwd_ws_bytes(d, x, y) : 0;
+}
+
 extern "C" int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
                              const float* bias, const coma_tensor* y, void* stream) {
+  return coma_conv_fwd_ws(d, x, wk, wk_dtype, bias, y, nullptr, 0, stream);
+}
+
+extern "C" int coma_conv_fwd_ws(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
+                                const float* bias, const coma_tensor* y, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = conv_check(d, x, y)) return rc;
   COMA_CHECK(wk, "conv_fwd: null weights");
   hipStream_t s = (hipStream_t)stream;
@@ -54,7 +64,7 @@ extern "C" int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, cons
     COMA_CHECK(wk_dtype == COMA_BF16, "conv_fwd: MFMA path needs bf16 kernel-layout weights");
     COMA_CHECK(conv_mfma_supported(d, x, y), "conv_fwd: shape not supported by the MFMA path (C=%d N=%d dtype=%d)",
                x->C, y->C, x->dtype);
-    return conv_mfma_fwd(d, x, wk, bias, y, s);
+    return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes);
   }
   COMA_CHECK(wk_dtype == COMA_F32, "conv_fwd: direct path needs fp32 kernel-layout weights");
   if (conv_point1_ok(d, x, y)) return conv_point1_fwd(d, x, (const float*)wk, bias, y, s);
@@ -78,7 +88,7 @@ extern "C" int coma_conv_fwd_norm_stats(const coma_conv_desc* d, const coma_tens
   if (coma_conv_pick_algo(d, x, y) == 2 && wk_dtype == COMA_BF16) {
     int chunks = 0;
     const int inst = mode == COMA_NORM_INSTANCE;
-    if (int rc = conv_mfma_fwd(d, x, wk, bias, y, s, (double2*)ws, inst, &chunks)) return rc;
+    if (int rc = conv_mfma_fwd(d, x, wk, bias, y, s, (double2*)ws, inst, &chunks, ws, ws_bytes)) return rc;
     if (chunks > 0) {
       const int G = inst ? y->B : 1;
       const int64_t R = inst ? t_vox(y) : t_vox(y) * y->B;

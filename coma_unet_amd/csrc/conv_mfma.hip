@@ -21,6 +21,8 @@ struct GatherP {
   const float* bias; int bsb;
   int k, stride, flip;
   int Mz, My, Mx;                      // M-grid (MODE 0: output grid; MODE 1: coarse grid)
+  int ksplit;                          // > 1: the K loop (taps x channel chunks) is cut into ksplit slices on blockIdx.y
+  float* part; long part_sb;           //      whose fp32 partial tiles are merged atomically into part[b][voxel][N]
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 2) | (chunk ^ ((row >> 2) & 3)); }  // 16-B slot index
@@ -64,8 +66,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int b = blockIdx.z;
-  int nblk, cls = 0;
-  if (MODE == 1) { cls = blockIdx.y & 7; nblk = blockIdx.y >> 3; } else { nblk = blockIdx.y; }
+  int nblk, cls = 0, ysl = blockIdx.y, ksi = 0;
+  if (p.ksplit > 1) { ksi = ysl % p.ksplit; ysl /= p.ksplit; }
+  if (MODE == 1) { cls = ysl & 7; nblk = ysl >> 3; } else { nblk = ysl; }
   const int n0 = nblk * BN;
   const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
   const long Mtot = (long)p.Mz * p.My * p.Mx;
@@ -104,12 +107,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
   const int cchunks = p.C >> 5;
   int ntaps;
   if (MODE == 0) ntaps = p.k * p.k * p.k; else ntaps = (1 + pz) * (1 + py) * (1 + px);
-  const int nsteps = ntaps * cchunks;
+  const int nsteps_all = ntaps * cchunks;
+  // split-K (deep layers: a few hundred voxels, thousands of K steps, fewer tiles than CUs): this block's slice
+  const int s_begin = p.ksplit > 1 ? (int)((long)nsteps_all * ksi / p.ksplit) : 0;
+  const int s_end = p.ksplit > 1 ? (int)((long)nsteps_all * (ksi + 1) / p.ksplit) : nsteps_all;
+  const int nsteps = s_end - s_begin;
+  if (nsteps <= 0) return;        // (block-uniform; the host keeps ksplit below every class's step count)
 
   uint4 ra[A_PIECES], rb[B_PIECES];
   // K-step counters advanced incrementally (no integer division in the loop)
-  int l_t = 0, l_cc = 0, l_jx = 0, l_jy = 0, l_jz = 0;
   const int l_nx = MODE == 0 ? p.k : 1 + px, l_ny = MODE == 0 ? p.k : 1 + py;
+  int l_t = s_begin / cchunks, l_cc = s_begin % cchunks;
+  int l_jx = l_t % l_nx, l_jy = (l_t / l_nx) % l_ny, l_jz = l_t / (l_nx * l_ny);
   auto load_step = [&](int) {
     const int t = l_t, cc = l_cc;
     int dz, dy, dx, wtap;
@@ -208,9 +217,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
       for (int e = 0; e < 16; ++e) {
         const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         const int off = rowoff[row];
-        if (off >= 0) yb[off + n] = static_cast<bf16_t>(acc[i][j][e] + bv);
+        if (off >= 0) {
+          if (p.ksplit > 1) atomicAdd(p.part + (long)b * p.part_sb + (long)(off / p.ldy) * p.N + n, acc[i][j][e]);
+          else yb[off + n] = static_cast<bf16_t>(acc[i][j][e] + bv);
+        }
       }
     }
+  }
+}
+
+// y[v][n] = bf16(part[v][n] + bias[n])  (the merge of the split-K partials)
+__global__ __launch_bounds__(256) void gather_finalize_k(const float* __restrict__ part, long part_sb, bf16_t* __restrict__ y, int ldy,
+                                                         long sby, int N, long V, const float* __restrict__ bias, int bsb) {
+  const int b = blockIdx.y;
+  const long total = V * N;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long v = e / N; const int n = (int)(e - v * N);
+    y[(long)b * sby + v * ldy + n] = static_cast<bf16_t>(part[(long)b * part_sb + e] + (bias ? bias[b * bsb + n] : 0.f));
   }
 }
 
@@ -796,6 +819,8 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 static bool halo_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   // stride-1 3x3x3 (either gather form); any channel counts; rows wide enough to fill 32-voxel M-tiles
+  // 8^3 grids with >= 32 channels both sides run faster on the gather kernel with split-K (512 -> 512: 97 vs 144 us)
+  if (x->W < 16 && x->C % 32 == 0 && y->C % 32 == 0) return false;
   return d->ksize == 3 && d->stride == 1 && x->W >= 8 && (long)x->H * x->W >= 32 &&
          (x->C >= 8 || y->C >= 8 || x->C * y->C >= 8);
 }
@@ -818,15 +843,44 @@ bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const co
   return true;
 }
 
+// split-K factor for a gather launch of `blocks` tiles and `nsteps` K steps (1 = no split)
+static int gather_ksplit(long blocks, int nsteps) {
+  // a block's K loop exposes one global-load latency per 32-channel step (8 MFMAs per wave): with one block per CU a
+  // deep layer is latency-bound, so the split aims at ~4 resident blocks per CU, not merely at filling the CUs
+  // (measured: more slices than this lose to their own atomic traffic -- every slice adds a full fp32 tile)
+  if (blocks >= 384 || nsteps < 16) return 1;
+  long ks = 512 / blocks;
+  if (ks > 8) ks = 8;
+  if (ks > nsteps / 4) ks = nsteps / 4;
+  return ks < 2 ? 1 : (int)ks;
+}
+
 template <int BN>
-static int launch_gather(const GatherP& p, int mode, int B, hipStream_t s) {
+static int launch_gather(const GatherP& p0, int mode, int B, hipStream_t s, void* ws, size_t ws_bytes) {
+  GatherP p = p0;
   constexpr int BM = (BN == 128) ? 128 : 256;
   const long Mtot = (long)p.Mz * p.My * p.Mx;
   const size_t lds = (size_t)2 * (BM + BN) * 64 + BM * 4;
-  dim3 grid((unsigned)((Mtot + BM - 1) / BM), (unsigned)(p.N / BN) * (mode == 1 ? 8 : 1), (unsigned)B);
+  const unsigned gx = (unsigned)((Mtot + BM - 1) / BM), gy = (unsigned)(p.N / BN) * (mode == 1 ? 8 : 1);
+  const long Vout = (long)p.Do * p.Ho * p.Wo;
+  const int ntaps_max = mode == 1 ? 8 : p.k * p.k * p.k;      // (mode 1: the 8-tap parity class bounds the split)
+  p.ksplit = gather_ksplit((long)gx * gy * B, (mode == 1 ? 1 : ntaps_max) * (p.C >> 5));
+  p.part = nullptr; p.part_sb = 0;
+  if (p.ksplit > 1 && ws && ws_bytes >= sizeof(float) * (size_t)B * Vout * p.N) {
+    p.part = (float*)ws; p.part_sb = Vout * p.N;
+    if (hipMemsetAsync(ws, 0, sizeof(float) * (size_t)B * Vout * p.N, s) != hipSuccess) { coma_set_error("conv split-K memset failed"); return 2; }
+  } else p.ksplit = 1;
+  dim3 grid(gx, gy * p.ksplit, (unsigned)B);
   if (mode == 0) hipLaunchKernelGGL((conv_mfma_gather_k<BN, 0>), grid, dim3(256), lds, s, p);
   else hipLaunchKernelGGL((conv_mfma_gather_k<BN, 1>), grid, dim3(256), lds, s, p);
   COMA_LAUNCH_CHECK();
+  if (p.ksplit > 1) {
+    long nb = (Vout * p.N + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(gather_finalize_k, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, (const float*)p.part, p.part_sb, p.y, p.ldy,
+                       p.sby, p.N, Vout, p.bias, p.bsb);
+    COMA_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -912,8 +966,15 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
   return launch_halo<32, 3, 0>(p, x->B, s);
 }
 
+// bytes of workspace with which the deep layers' K loop may be split over more blocks (0: never split)
+size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  if (halo_ok(d, x, y) || pw_ok(d, x, y)) return 0;
+  return sizeof(float) * (size_t)y->B * t_vox(y) * y->C <= ((size_t)64 << 20) ? sizeof(float) * (size_t)y->B * t_vox(y) * y->C : 0;
+}
+
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
-                  const coma_tensor* y, hipStream_t s, double2* stats, int stats_inst, int* stats_chunks) {
+                  const coma_tensor* y, hipStream_t s, double2* stats, int stats_inst, int* stats_chunks, void* ws,
+                  size_t ws_bytes) {
   if (halo_ok(d, x, y)) return conv_mfma_halo(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
   if (pw_ok(d, x, y) && !(x->C % 32 == 0 && y->C % 32 == 0 && x->C * y->C > 64 * 32)) {
     COMA_CHECK(aligned16(wk), "conv_mfma: weights must be 16-byte aligned");
@@ -957,9 +1018,9 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
   } else {
     p.Mz = y->D; p.My = y->H; p.Mx = y->W;
   }
-  if (y->C % 128 == 0) return launch_gather<128>(p, mode, x->B, s);
-  if (y->C % 64 == 0) return launch_gather<64>(p, mode, x->B, s);
-  return launch_gather<32>(p, mode, x->B, s);
+  if (y->C % 128 == 0) return launch_gather<128>(p, mode, x->B, s, ws, ws_bytes);
+  if (y->C % 64 == 0) return launch_gather<64>(p, mode, x->B, s, ws, ws_bytes);
+  return launch_gather<32>(p, mode, x->B, s, ws, ws_bytes);
 }
 
 // =====================================================================================

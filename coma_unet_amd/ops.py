@@ -258,16 +258,17 @@ def _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm):
     kind = conv_class("mfma" if wk_f.dtype == torch.bfloat16 else "direct", x.shape[4], n)
     d = _desc(ksize, stride, form, per_sample, algo)
     tag = (tuple(x.shape), n, ksize, stride, form)
+    cx, cy = ct(x), ct(y)
     if norm is None:
+        ws = workspace(lib.coma_conv_fwd_ws_bytes(d, cx, cy), x.device)      # split-K scratch of the deep layers
         KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
-                        lambda: check(lib.coma_conv_fwd(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), ct(y),
-                                                        L.stream()), "coma_conv_fwd"), tag=tag)
+                        lambda: check(lib.coma_conv_fwd_ws(d, cx, ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), cy, ptr(ws),
+                                                           ws.numel(), L.stream()), "coma_conv_fwd"), tag=tag)
         return y, None, None
     mode, eps, rmean, rvar, momentum = norm
     G = B if mode == L.NORM_INSTANCE else 1
     mean, rstd = _f32((G, n), x.device), _f32((G, n), x.device)
-    cy = ct(y)
-    ws = workspace(lib.coma_norm_ws_bytes(cy), x.device)
+    ws = workspace(max(lib.coma_norm_ws_bytes(cy), lib.coma_conv_fwd_ws_bytes(d, cx, cy)), x.device)
     KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
                     lambda: check(lib.coma_conv_fwd_norm_stats(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), cy,
                                                                mode, eps, ptr(mean), ptr(rstd), ptr(rmean), ptr(rvar),
@@ -286,11 +287,12 @@ def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_d
     if need_dx:
         assert wk_d is not None, "data gradient requested but dgrad weights were not prepared"
         dx = _new(x.shape, x.dtype, x.device)
+        dd, cdy_, cdx = _desc(ksize, stride, 1 - form, per_sample, algo), ct(dy), ct(dx)
+        wsd = workspace(lib.coma_conv_fwd_ws_bytes(dd, cdy_, cdx), x.device)
         KernelTimer.run("conv_dgrad", conv_class("mfma" if wk_d.dtype == torch.bfloat16 else "direct", dy.shape[4], x.shape[4]),
                         conv_flops(dy.shape, dx.shape, ksize, stride),
-                        lambda: check(lib.coma_conv_fwd(_desc(ksize, stride, 1 - form, per_sample, algo), ct(dy),
-                                                        ptr(wk_d), L.dtype_code(wk_d.dtype), None, ct(dx), s),
-                                      "coma_conv_fwd(dgrad)"), tag=tag)
+                        lambda: check(lib.coma_conv_fwd_ws(dd, cdy_, ptr(wk_d), L.dtype_code(wk_d.dtype), None, cdx, ptr(wsd),
+                                                           wsd.numel(), s), "coma_conv_fwd(dgrad)"), tag=tag)
     if need_dw:
         d = _desc(ksize, stride, form, per_sample, algo)
         cx, cdy = ct(x), ct(dy)

@@ -114,6 +114,12 @@ int coma_routing_bwd(const float* cov, int32_t B, int32_t NC, const float* r, in
 int coma_conv_pick_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
                   int32_t wk_dtype, const float* bias, const coma_tensor* y, void* stream);
+/* coma_conv_fwd with a scratch buffer: layers with fewer output tiles than CUs (8^3 / 16^3 grids, 256-512 channels)
+ * split their K loop (taps x channel chunks) over more blocks, merge fp32 partials in `ws` and convert once.
+ * ws_bytes >= coma_conv_fwd_ws_bytes(...) enables it; a smaller or NULL ws runs the unsplit kernel.          */
+size_t coma_conv_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
+int coma_conv_fwd_ws(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
+                     const float* bias, const coma_tensor* y, void* ws, size_t ws_bytes, void* stream);
 /* conv forward + statistics of the BatchNorm(train)/InstanceNorm that follows it (MONAI Convolution =
  * conv -> ADN): the partial sums come out of the conv epilogue where the kernel supports it, so the conv
  * output is not re-read.  Arguments as coma_conv_fwd + coma_norm_stats (ws >= coma_norm_ws_bytes(y)).   */
