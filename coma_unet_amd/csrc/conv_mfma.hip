@@ -1054,6 +1054,7 @@ struct WgradP2 {
   int cblocks;         // ceil(C / (32*TC))
   int vec_n, vec_c;    // 16-byte loads legal on dy / x
   unsigned m_hx, m_hxy; // magic multipliers: n / hx == umulhi(n, m_hx), n / (hx*hy) == umulhi(n, m_hxy)
+  int plain;           // every dwk element is produced by exactly one block: plain stores, no memset, no atomics
 };
 
 template <int TN, int TC, int FORM, int VEC>
@@ -1218,7 +1219,10 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
           for (int e = 0; e < 16; ++e) {
             const int n = n0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
             const int c = c0 + j * 32 + fr;
-            if (n < p.N && c < p.C) atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, acc[t][i][j][e]);
+            if (n < p.N && c < p.C) {
+              if (p.plain) wout[((long)tap * p.N + n) * p.C + c] = acc[t][i][j][e];
+              else atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, acc[t][i][j][e]);
+            }
           }
     }
   }
@@ -1554,10 +1558,17 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   // one block per CU: aim for ~512 blocks, but never split the voxels further than needed to fill the chip --
   // every extra chunk costs a full 27 x n x c fp32 atomic merge (~1.3 TB/s chip-wide)
   int chunks = 512 / (pairs * x->B);
+  // Deepest layers (>= 64 weight tiles, <= 1024 voxels): ONE block per tile and sample.  With per-sample weights (or one sample) every
+  // dwk element then has a single producer: plain stores instead of memset + fp32 atomics (512 -> 512 at 8^3: the
+  // 28 M atomics of a 2-chunk split cost ~90 of the kernel's 142 us).
+  // (measured: at <= 1024 dense voxels a quarter of the CUs busy without atomics beats all of them with; at 4096
+  // voxels the single block's MFMA work is the longer pole and the old split wins)
+  if (pairs * x->B >= 64 && (long)p.Mz * p.My * p.Mx <= 1024) chunks = 1;
   if (chunks < 1) chunks = 1;
   if (chunks > p.tiles_total) chunks = p.tiles_total;
   p.tiles_per_block = (p.tiles_total + chunks - 1) / chunks;
   chunks = (p.tiles_total + p.tiles_per_block - 1) / p.tiles_per_block;
+  p.plain = chunks == 1 && (d->per_sample_w || x->B == 1);
   pl.grid = dim3((unsigned)chunks, (unsigned)pairs, (unsigned)x->B);
   const long taps = (long)d->ksize * d->ksize * d->ksize;
   p.wsb = d->per_sample_w ? taps * p.N * p.C : 0;
@@ -1580,7 +1591,7 @@ int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_te
   COMA_CHECK(pl.ok, "conv_mfma_wgrad: unsupported problem");
   pl.p.dwk = dwk;
   const long wsz = (long)d->ksize * d->ksize * d->ksize * dy->C * x->C * (d->per_sample_w ? x->B : 1);
-  if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  if (!pl.p.plain && hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
   const bool vecall = pl.p.vec_n && pl.p.vec_c && dy->C % 8 == 0 && x->C % 8 == 0;
 #define WL(TNV, TCV, F)                                                                                          \
   do {                                                                                                           \

@@ -336,6 +336,8 @@ MFMA_CASES = [
     # persistent halo kernel (W >= 32): resident weights (C == 32) and streamed kz-planes (C > 32), ragged grids
     (32, 32, 3, 1, False, (20, 21, 70)), (32, 64, 3, 1, False, (17, 10, 33)), (64, 32, 3, 1, False, (18, 9, 64)),
     (96, 64, 3, 1, False, (3, 5, 40)), (32, 96, 3, 1, False, (35, 4, 32)),
+    # deep layers: split-K forward / data-gradient, single-producer (plain-store) weight-gradient tiles
+    (512, 384, 3, 1, False, (4, 4, 8)), (256, 512, 3, 2, False, (4, 6, 8)), (512, 256, 3, 2, True, (2, 3, 4)),
 ]
 
 
