@@ -1465,7 +1465,9 @@ static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const
   const int pairs = ((p.N + 31) / 32) * p.cblocks;
   p.vec_n = dy->ld % 8 == 0 && dy->sb % 8 == 0 && (((uintptr_t)dy->data) & 15) == 0;
   p.vec_c = x->ld % 8 == 0 && x->sb % 8 == 0 && (((uintptr_t)x->data) & 15) == 0;
-  int chunks = 1024 / (pairs * x->B);
+  // 512 blocks = the 2 resident blocks per CU, once: every block ends with a 27 x 32 x 32 fp32 atomic merge, and a second
+  // round of blocks doubled that traffic (64 -> 64 at 64^3: 215 -> 156 us, 128 -> 128 at 32^3: 136 -> 101 us)
+  int chunks = 512 / (pairs * x->B);
   if (chunks < 1) chunks = 1;
   if (chunks > p.tiles_total) chunks = p.tiles_total;
   p.tiles_per_block = (p.tiles_total + chunks - 1) / chunks;
