@@ -208,6 +208,16 @@ int coma_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
                float beta2, float eps, float weight_decay, int32_t step, const int32_t* step_dev,
                void* stream);
 
+/* ---- input pipeline (replaces VolumeDataset_ADNI_A4_combined.py:95-133,:62) ----
+ * Nearest-neighbour resample of a raw fp32 (z, y, x) volume with voxel spacing sp_* (mm) onto a Do x Ho x Wo grid with
+ * spacing nsp_* (same origin and axes, identity transform, ITK rounding), optional nan_to_num, optional zeroing where
+ * the dst-sized volume `zero_where` is 0 (the reference's `mri[roi == 0] = 0`).  Out-of-volume samples take
+ * default_value (the reference passes the image's SimpleITK pixel-type id there).                              */
+int coma_resample_nearest(const float* src, int32_t Dz, int32_t Hy, int32_t Wx, double sp_z, double sp_y,
+                          double sp_x, float* dst, int32_t Do, int32_t Ho, int32_t Wo, double nsp_z,
+                          double nsp_y, double nsp_x, float default_value, int32_t nan_to_num,
+                          const float* zero_where, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
