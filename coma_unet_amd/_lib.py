@@ -68,6 +68,8 @@ SIGNATURES = {
     "coma_l1_fwd": (_i32, [_TP, _TP, _vp, _vp, _sz, _vp]),
     "coma_l1_bwd": (_i32, [_TP, _TP, _vp, _TP, _vp]),
     "coma_eval_stats": (_i32, [_TP, _TP, _TP, _vp, _i32, _vp, _vp]),
+    "coma_ssim_ws_bytes": (_sz, [_TP, _i32]),
+    "coma_ssim_partial": (_i32, [_TP, _TP, _vp, _i32, _f32, _f32, _vp, _sz, _vp, _vp]),
     "coma_resample_nearest": (_i32, [_vp, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _vp, _i32, _i32, _i32,
                               C.c_double, C.c_double, C.c_double, _f32, _i32, _vp, _vp]),
     "coma_adamw": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),

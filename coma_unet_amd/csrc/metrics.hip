@@ -131,3 +131,117 @@ extern "C" int coma_resample_nearest(const float* src, int32_t Dz, int32_t Hy, i
   COMA_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3-D SSIM (the reference's `SSIMMetric(spatial_dims=3, data_range=1)` from MONAI, attn_unet_data_parallel.py:1176,1234):
+// windowed means of x, y, x^2, y^2, xy with a separable window ("valid" region, no padding), then
+//   ssim = (2 mu_x mu_y + c1) / (mu_x^2 + mu_y^2 + c1) * (2 s_xy + c2) / (s_x + s_y + c2),
+// averaged over the valid voxels of each sample.  One block = one 8^3 tile of outputs: its (8 + win - 1)^3 input cube is
+// read once, the three separable passes run in LDS, and the block emits one fp64 partial sum.
+// ---------------------------------------------------------------------------------------------------------------------
+#define SSIM_T 8
+#define SSIM_MAXW 11
+struct SsimP {
+  const void* x; int64_t ldx, sbx;
+  const void* y; int64_t ldy, sby;
+  int D, H, W, win;
+  int ntx, nty, ntz;
+  float c1, c2;
+  float w[SSIM_MAXW];
+  double* partial;      // [B][ntiles]
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void ssim_partial_k(SsimP p) {
+  constexpr int TO = SSIM_T, TI = SSIM_T + SSIM_MAXW - 1;       // outputs / inputs per axis (input extent used: TO + win - 1)
+  __shared__ float in_[2][TI][TI][TI];                          // x, y cubes                        (2 * 18^3 * 4 = 46.7 KB)
+  __shared__ float px[5][TI][TI][TO];                           // after the x pass: 5 quantities    (5 * 18*18*8 * 4 = 51.8 KB)
+  __shared__ float py[5][TI][TO][TO];                           // after the y pass                  (23 KB)
+  __shared__ double red[256];
+  const int b = blockIdx.y;
+  int t = blockIdx.x;
+  const int tx = t % p.ntx; t /= p.ntx;
+  const int ty = t % p.nty; const int tz = t / p.nty;
+  const int x0 = tx * TO, y0 = ty * TO, z0 = tz * TO;
+  const int ext = TO + p.win - 1;
+  const int Do = p.D - p.win + 1, Ho = p.H - p.win + 1, Wo = p.W - p.win + 1;
+  const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.sbx;
+  const T* yb = reinterpret_cast<const T*>(p.y) + (int64_t)b * p.sby;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < ext * ext * ext; i += 256) {
+    const int ix = i % ext, iy = (i / ext) % ext, iz = i / (ext * ext);
+    const int gx = x0 + ix, gy = y0 + iy, gz = z0 + iz;
+    float a = 0.f, c = 0.f;
+    if (gx < p.W && gy < p.H && gz < p.D) {
+      const int64_t v = ((int64_t)gz * p.H + gy) * p.W + gx;
+      a = ld_f(xb + v * p.ldx); c = ld_f(yb + v * p.ldy);
+    }
+    in_[0][iz][iy][ix] = a; in_[1][iz][iy][ix] = c;
+  }
+  __syncthreads();
+  for (int i = tid; i < ext * ext * TO; i += 256) {             // x pass
+    const int ox = i % TO, iy = (i / TO) % ext, iz = i / (TO * ext);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    for (int k = 0; k < p.win; ++k) {
+      const float a = in_[0][iz][iy][ox + k], c = in_[1][iz][iy][ox + k], w = p.w[k];
+      s0 = fmaf(w, a, s0); s1 = fmaf(w, c, s1); s2 = fmaf(w, a * a, s2); s3 = fmaf(w, c * c, s3); s4 = fmaf(w, a * c, s4);
+    }
+    px[0][iz][iy][ox] = s0; px[1][iz][iy][ox] = s1; px[2][iz][iy][ox] = s2; px[3][iz][iy][ox] = s3; px[4][iz][iy][ox] = s4;
+  }
+  __syncthreads();
+  for (int i = tid; i < 5 * ext * TO * TO; i += 256) {          // y pass
+    const int ox = i % TO, oy = (i / TO) % TO, iz = (i / (TO * TO)) % ext, q = i / (TO * TO * ext);
+    float s = 0.f;
+    for (int k = 0; k < p.win; ++k) s = fmaf(p.w[k], px[q][iz][oy + k][ox], s);
+    py[q][iz][oy][ox] = s;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int i = tid; i < TO * TO * TO; i += 256) {               // z pass + SSIM
+    const int ox = i % TO, oy = (i / TO) % TO, oz = i / (TO * TO);
+    if (x0 + ox < Wo && y0 + oy < Ho && z0 + oz < Do) {
+      float m[5];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        float s = 0.f;
+        for (int k = 0; k < p.win; ++k) s = fmaf(p.w[k], py[q][oz + k][oy][ox], s);
+        m[q] = s;
+      }
+      const float sx = m[2] - m[0] * m[0], sy = m[3] - m[1] * m[1], sxy = m[4] - m[0] * m[1];
+      const float cs = (2.f * sxy + p.c2) / (sx + sy + p.c2);
+      acc += (double)(((2.f * m[0] * m[1] + p.c1) / (m[0] * m[0] + m[1] * m[1] + p.c1)) * cs);
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) p.partial[(int64_t)b * gridDim.x + blockIdx.x] = red[0];
+}
+
+extern "C" size_t coma_ssim_ws_bytes(const coma_tensor* x, int32_t win) {
+  if (win < 1 || x->D < win || x->H < win || x->W < win) return 0;
+  const int64_t nt = (int64_t)((x->D - win + SSIM_T) / SSIM_T) * ((x->H - win + SSIM_T) / SSIM_T) * ((x->W - win + SSIM_T) / SSIM_T);
+  return (size_t)x->B * nt * sizeof(double);
+}
+
+// partial sums [B][ntiles] (fp64) of the SSIM map over the valid region; *ntiles_out receives the tile count per sample.
+extern "C" int coma_ssim_partial(const coma_tensor* x, const coma_tensor* y, const float* window, int32_t win, float c1, float c2,
+                                 double* partial, size_t partial_bytes, int32_t* ntiles_out, void* stream) {
+  COMA_CHECK(x && y && x->data && y->data && window && partial && ntiles_out, "ssim: null argument");
+  COMA_CHECK(t_same_grid(x, y) && x->C == 1 && y->C == 1 && x->dtype == y->dtype, "ssim: single-channel volumes of equal shape expected");
+  COMA_CHECK(win >= 1 && win <= SSIM_MAXW && x->D >= win && x->H >= win && x->W >= win, "ssim: window %d does not fit", win);
+  COMA_CHECK(partial_bytes >= coma_ssim_ws_bytes(x, win), "ssim: partial buffer too small");
+  SsimP p;
+  p.x = x->data; p.ldx = x->ld; p.sbx = x->sb; p.y = y->data; p.ldy = y->ld; p.sby = y->sb;
+  p.D = x->D; p.H = x->H; p.W = x->W; p.win = win; p.c1 = c1; p.c2 = c2;
+  for (int k = 0; k < SSIM_MAXW; ++k) p.w[k] = k < win ? window[k] : 0.f;
+  p.ntz = (x->D - win + SSIM_T) / SSIM_T; p.nty = (x->H - win + SSIM_T) / SSIM_T; p.ntx = (x->W - win + SSIM_T) / SSIM_T;
+  p.partial = partial;
+  const int nt = p.ntx * p.nty * p.ntz;
+  *ntiles_out = nt;
+  dim3 grid((unsigned)nt, (unsigned)x->B);
+  if (x->dtype == COMA_F32) hipLaunchKernelGGL(ssim_partial_k<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(ssim_partial_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}

@@ -5,9 +5,11 @@ The reference walks 36 ROIs in Python and runs ~7 masked full-volume reductions 
 ONE HIP kernel (``coma_eval_stats``) reads (pred, tau, roi) once and emits, per sample and per bin
 (36 ROIs + whole volume), the eight fp64 sums every one of those metrics is a closed-form function of; the
 remaining arithmetic runs on a (B, 37, 8) table.  Function names and return contracts follow the reference.
-SSIM (MONAI ``SSIMMetric``, third party, unpinned) is not implemented.
+SSIM: ``SSIMMetric`` below restates MONAI's (third party, unpinned upstream) on a fused tile kernel.
 """
 from __future__ import annotations
+
+import ctypes
 
 import numpy as np
 import torch
@@ -87,3 +89,61 @@ class RoiCorrMetric:
 
     def calc_roi_corr(self):
         return np.array([np.corrcoef(self.pred_means[i], self.gt_means[i])[0, 1] for i in range(len(self.roi_indices))])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SSIM (attn_unet_data_parallel.py:23,1176-1178,1234-1239,1300: monai.metrics.regression.SSIMMetric)
+# ---------------------------------------------------------------------------------------------------------------------
+def ssim_window(kernel_type="gaussian", win_size=11, kernel_sigma=1.5):
+    """1-D separable window; MONAI builds the n-D kernel as the outer product of these."""
+    if kernel_type == "gaussian":
+        dist = np.arange((1 - win_size) / 2, (1 + win_size) / 2, 1.0)
+        g = np.exp(-np.square(dist / kernel_sigma) / 2.0)
+        return (g / g.sum()).astype(np.float32)
+    if kernel_type == "uniform":
+        return np.full((win_size,), 1.0 / win_size, dtype=np.float32)
+    raise ValueError(kernel_type)
+
+
+def ssim3d(y_pred, y, data_range=1.0, kernel_type="gaussian", win_size=11, kernel_sigma=1.5, k1=0.01, k2=0.03):
+    """Per-sample SSIM (B,) fp64 of (B, 1, D, H, W) volumes: windowed statistics over the un-padded ("valid") region, the
+    formulas of MONAI >= 1.2 `compute_ssim_and_cs`.  (MONAI <= 1.1, whose constructor signature the reference's call
+    matches as well, used a uniform 7^3 window with an unbiased-covariance factor; the dependency is unpinned upstream.)"""
+    assert y_pred.shape == y.shape and y_pred.dim() == 5 and y_pred.shape[1] == 1
+    w = ssim_window(kernel_type, win_size, kernel_sigma)
+    p = _vol(y_pred.detach())
+    t = _vol(y, p.dtype)
+    cp, ctt = ct(p), ct(t)
+    nbytes = lib.coma_ssim_ws_bytes(cp, win_size)
+    assert nbytes > 0, "volume smaller than the SSIM window"
+    part = torch.empty(nbytes // 8, dtype=torch.float64, device=p.device)
+    nt = ctypes.c_int32(0)
+    dr = float(data_range)
+    check(lib.coma_ssim_partial(cp, ctt, w.ctypes.data_as(ctypes.c_void_p), win_size, (k1 * dr) ** 2, (k2 * dr) ** 2, ptr(part),
+                                nbytes, ctypes.addressof(nt), L.stream()), "coma_ssim_partial")
+    B, D, H, W = p.shape[0], p.shape[1], p.shape[2], p.shape[3]
+    nvalid = (D - win_size + 1) * (H - win_size + 1) * (W - win_size + 1)
+    return part.view(B, nt.value).sum(1) / nvalid
+
+
+class SSIMMetric:
+    """MONAI's cumulative metric surface as the reference uses it: `m(y_pred=..., y=...)` per batch, `aggregate()`,
+    `reset()` (:1234,1300-1301)."""
+
+    def __init__(self, spatial_dims=3, data_range=1.0, kernel_type="gaussian", win_size=11, kernel_sigma=1.5, k1=0.01, k2=0.03,
+                 reduction="mean"):
+        assert spatial_dims == 3 and reduction == "mean"
+        self.data_range = float(data_range.reshape(-1)[0]) if torch.is_tensor(data_range) else float(data_range)
+        self.kw = dict(kernel_type=kernel_type, win_size=win_size, kernel_sigma=kernel_sigma, k1=k1, k2=k2)
+        self._vals = []
+
+    def __call__(self, y_pred, y):
+        v = ssim3d(y_pred, y, self.data_range, **self.kw)
+        self._vals.append(v)
+        return v.unsqueeze(1).float()
+
+    def aggregate(self):
+        return torch.cat(self._vals).mean().float()      # mean over every sample seen since reset()
+
+    def reset(self):
+        self._vals = []

@@ -208,6 +208,14 @@ int coma_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
                float beta2, float eps, float weight_decay, int32_t step, const int32_t* step_dev,
                void* stream);
 
+/* ---- 3-D SSIM (MONAI SSIMMetric(spatial_dims=3), attn_unet_data_parallel.py:1176,1234) ----
+ * x, y: single-channel volumes; window: `win` (<= 11) separable weights (host pointer); c1 = (k1 R)^2, c2 = (k2 R)^2.
+ * Writes one fp64 partial sum of the SSIM map per 8^3 output tile: partial[b * ntiles + t]; the per-sample SSIM is
+ * sum_t partial / ((D-win+1)(H-win+1)(W-win+1)).                                                              */
+size_t coma_ssim_ws_bytes(const coma_tensor* x, int32_t win);
+int coma_ssim_partial(const coma_tensor* x, const coma_tensor* y, const float* window, int32_t win, float c1,
+                      float c2, double* partial, size_t partial_bytes, int32_t* ntiles_out, void* stream);
+
 /* ---- input pipeline (replaces VolumeDataset_ADNI_A4_combined.py:95-133,:62) ----
  * Nearest-neighbour resample of a raw fp32 (z, y, x) volume with voxel spacing sp_* (mm) onto a Do x Ho x Wo grid with
  * spacing nsp_* (same origin and axes, identity transform, ITK rounding), optional nan_to_num, optional zeroing where

@@ -76,3 +76,26 @@ class RoiCorrMetric:   # :36-96 (accumulation + correlation only; CSV dumps are 
 
     def calc_roi_corr(self):
         return np.array([np.corrcoef(self.pred_means[i], self.gt_means[i])[0, 1] for i in range(len(self.roi_indices))])
+
+
+
+def ssim3d(y_pred, y, data_range=1.0, kernel_type="gaussian", win_size=11, kernel_sigma=1.5, k1=0.01, k2=0.03):
+    """MONAI >= 1.2 `compute_ssim_and_cs` + per-sample mean (monai/metrics/regression.py), restated from its published
+    source with stock torch ops (the dependency itself is absent and unpinned upstream: PARITY UNPINNED).  fp64."""
+    import torch
+    import torch.nn.functional as F
+    x, t = y_pred.double(), y.double()
+    if kernel_type == "gaussian":
+        dist = torch.arange((1 - win_size) / 2, (1 + win_size) / 2, 1.0, dtype=torch.float64)
+        g = torch.exp(-torch.pow(dist / kernel_sigma, 2) / 2)
+        w1 = g / g.sum()
+    else:
+        w1 = torch.full((win_size,), 1.0 / win_size, dtype=torch.float64)
+    k = (w1[:, None, None] * w1[None, :, None] * w1[None, None, :])[None, None]
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    mu_x, mu_y = F.conv3d(x, k), F.conv3d(t, k)
+    mu_xx, mu_yy, mu_xy = F.conv3d(x * x, k), F.conv3d(t * t, k), F.conv3d(x * t, k)
+    sx, sy, sxy = mu_xx - mu_x * mu_x, mu_yy - mu_y * mu_y, mu_xy - mu_x * mu_y
+    cs = (2 * sxy + c2) / (sx + sy + c2)
+    full = ((2 * mu_x * mu_y + c1) / (mu_x ** 2 + mu_y ** 2 + c1)) * cs
+    return full.reshape(full.shape[0], -1).mean(1)

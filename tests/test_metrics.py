@@ -61,3 +61,29 @@ def test_eval_stats_kernel_vs_oracle(dtype):
     a, r = c_got.calc_roi_corr(), c_ref.calc_roi_corr()
     ok = np.isfinite(r)
     assert np.allclose(a[ok], r[ok], atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,kernel_type,win", [((2, 1, 24, 20, 27), "gaussian", 11), ((1, 1, 16, 33, 18), "uniform", 7),
+                                                   ((3, 1, 12, 12, 12), "gaussian", 11)])
+def test_ssim_matches_oracle(shape, kernel_type, win):
+    """3-D SSIM tile kernel vs the restated MONAI formulas (fp64 torch convs); fp32 window arithmetic: 1e-4 absolute."""
+    from coma_unet_amd import metrics as M
+    from oracle import metrics_oracle as O
+    g = torch.Generator().manual_seed(sum(shape))
+    y = torch.rand(shape, generator=g)
+    p = (y + 0.15 * torch.randn(shape, generator=g)).clamp(0, 1)
+    want = O.ssim3d(p, y, 1.0, kernel_type, win)
+    got = M.ssim3d(p.cuda(), y.cuda(), 1.0, kernel_type, win).cpu()
+    assert got.shape == want.shape and float((got - want).abs().max()) < 1e-4, (got, want)
+    same = M.ssim3d(y.cuda(), y.cuda(), 1.0, kernel_type, win).cpu()
+    assert float((same - 1).abs().max()) < 1e-5                      # identical volumes: SSIM = 1
+    m = M.SSIMMetric(spatial_dims=3, data_range=torch.tensor([1.0]), kernel_type=kernel_type, win_size=win)
+    m(y_pred=p.cuda(), y=y.cuda()); m(y_pred=y.cuda(), y=y.cuda())
+    assert abs(float(m.aggregate()) - float(torch.cat([want, torch.ones(shape[0], dtype=torch.float64)]).mean())) < 1e-4
+    m.reset()
+    assert m._vals == []
+    # bf16 prediction volumes (what the bf16 model emits) go through the same kernel
+    gb = M.ssim3d(p.cuda().bfloat16(), y.cuda(), 1.0, kernel_type, win).cpu()
+    wb = O.ssim3d(p.bfloat16().float(), y.bfloat16().float(), 1.0, kernel_type, win)
+    assert float((gb - wb).abs().max()) < 1e-3
