@@ -366,3 +366,33 @@ def test_checkpoint_roundtrip_and_plateau_scheduler(tmp_path):
     g()
     assert g._captured_hyper[0] == 0.0
     assert all(torch.equal(p, before[n]) for n, p in gm3.named_parameters())
+
+
+def test_noncubic_volume_odd_batch():
+    """Shapes the tiling has to cope with beyond the cubes of the BASELINE configs: a 32 x 48 x 64 volume, batch 3 --
+    fp32 forward + loss against the oracle, then bf16 eager and graph-replayed train steps (finite, decreasing)."""
+    import coma_unet_amd as cu
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import forward_loss, train_step, make_optimizer, GraphedTrainStep
+    from oracle.criterions_oracle import build_reference_criterion, train_step_loss
+    S, B = (32, 48, 64), 3
+    om, gm = _pair(S, 77)
+    b = make_batch(B, S, seed=17)
+    with torch.no_grad():
+        losses, outs = forward_loss(gm, cu.build_reference_criterion(), _gpu_batch(b))
+        ref = om(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])
+        ref_total = train_step_loss(ref, b["tau"], b["roi"], b["covars"], build_reference_criterion())[0]
+    assert rel(outs[0], ref[0]) < 1e-3
+    assert abs(float(losses[0]) - float(ref_total)) <= 1e-3 * abs(float(ref_total))
+    torch.manual_seed(8)
+    gb16 = cu.build_model(volume_shape=S, static_prompts=True, compute_dtype=torch.bfloat16).cuda()
+    gb16.set_save_attn(None)
+    gb16.train(True)
+    gb = _gpu_batch(b)
+    gb["roi_pred_dicts"] = gb16._priors(b["roi_pred_dicts"], B, torch.device("cuda"))
+    opt = make_optimizer(gb16, 1e-3)
+    crit = cu.build_reference_criterion()
+    l0 = float(train_step(gb16, crit, opt, gb)[0][0])
+    step = GraphedTrainStep(gb16, crit, opt, gb, warmup=2)
+    ls = [float(step()[0][0]) for _ in range(4)]
+    assert all(np.isfinite(v) for v in [l0] + ls) and ls[-1] < l0
