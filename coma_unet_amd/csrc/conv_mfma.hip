@@ -554,6 +554,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   load_halo(tiz * TZ, tiy * TY, tix * TX, 0);
   if (!RESIDENT) load_w(0, 0);
 
+  const bool has_bias = p.bias != nullptr, do_stats = p.stats != nullptr;
   float bv[4][4];
   float st_s[4][4], st_q[4][4];     // fused norm statistics of this lane's 16 channels (stored values)
 #pragma unroll
@@ -573,10 +574,12 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
     const bool has_next = nid < id_end;
 
     f32x16_t acc[2];
+    if (!(RESIDENT && OCC == 2)) {   // (thin variant: one chunk, the first MFMA of the tile takes a literal-zero C operand)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    }
 
     for (int cc = 0; cc < nchunks; ++cc) {
       __syncthreads();                       // all waves finished reading the previous halo / weights
@@ -604,9 +607,12 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+              const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
               acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wv[t & 1][ks]),
-                                                               *reinterpret_cast<const bf16x8_t*>(&xv[t & 1][i][ks]), acc[i], 0, 0, 0);
+                                                               *reinterpret_cast<const bf16x8_t*>(&xv[t & 1][i][ks]),
+                                                               (OCC == 2 && t == 0 && ks == 0) ? zero : acc[i], 0, 0, 0);
+            }
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -654,12 +660,21 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
         bf16_t* dst = yb + ((long)(gz * p.H + gy) * p.W + gx) * p.ldy + n0 + 4 * fh;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
+          // wave-uniform skips: at one or two waves per SIMD this VALU work is not hidden behind anything, so channel
+          // groups past N (zero padding of the thin layers), the bias add of a data-gradient call and the statistics
+          // of a call that did not ask for them are not computed at all
+          // (thin variant only: on the one-block-per-CU kernel the same branches measured +15 %)
+          if (OCC == 2 && n0 + 8 * g4 >= p.N) continue;
           bf16_t o[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            o[q] = static_cast<bf16_t>(acc[i][g4 * 4 + q] + bv[g4][q]);
-            const float r = static_cast<float>(o[q]);
-            st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]);
+            float a = acc[i][g4 * 4 + q];
+            if (OCC != 2 || has_bias) a += bv[g4][q];
+            o[q] = static_cast<bf16_t>(a);
+            if (OCC != 2 || do_stats) {
+              const float r = static_cast<float>(o[q]);
+              st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]);
+            }
           }
           if (p.st8 && n0 + 8 * g4 + 4 * fh + 3 < p.N) *reinterpret_cast<uint2*>(dst + 8 * g4) = *reinterpret_cast<uint2*>(o);
           else {
