@@ -172,9 +172,13 @@ __global__ __launch_bounds__(256) void weight_prep_bwd_k(const float* dwk, const
       g[b][t] = (live && b < Bw) ? dwk[((int64_t)b * TAPS + t) * N * C + i] : 0.f;
   for (int e = 0; e < E; ++e) {
     const int64_t off = e * se + n * sn + c * sc;
-    float w[TAPS];
+    float w[TAPS];        // the expert's weights are only needed for dr; one guarded block so the 27 loads merge into dwordx4
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) w[t] = live ? master[off + t] : 0.f;
+    for (int t = 0; t < TAPS; ++t) w[t] = 0.f;
+    if (live && dr) {
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) w[t] = master[off + t];
+    }
     float dm[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) dm[t] = 0.f;
