@@ -256,6 +256,17 @@ __device__ __forceinline__ uint4 load8(const bf16_t* ptr, int nvalid, bool vec) 
                     e[6] | ((unsigned)e[7] << 16));
 }
 
+// The same piece WITHOUT the mask when the vector access is legal: a prefetch must not consume its data (the mask would
+// put an s_waitcnt vmcnt(0) behind every load and serialise a tile's 13 loads); apply mask8() when the piece is stored.
+__device__ __forceinline__ uint4 load8_raw(const bf16_t* ptr, int nvalid, bool vec) {
+  if (vec) return *reinterpret_cast<const uint4*>(ptr);
+  return load8(ptr, nvalid, false);
+}
+__device__ __forceinline__ uint4 mask8(int nvalid) {
+  auto m = [&](int j) -> unsigned { const int k = nvalid - 2 * j; return k >= 2 ? 0xffffffffu : (k == 1 ? 0xffffu : 0u); };
+  return make_uint4(m(0), m(1), m(2), m(3));
+}
+
 // =====================================================================================
 // Stride-1 3x3x3 convolution (forward, and data-gradient via `flip`) with the input HALO
 // staged once per channel chunk in LDS: a block owns 8 M-tiles (2 z-planes x 4 row groups of
@@ -1381,7 +1392,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
         dv[it] = make_uint4(0, 0, 0, 0);
         if (gz < p.D && gy < p.H && gx < p.W) {
           const bf16_t* src = dyb + (unsigned)(((gz * p.H + gy) * p.W + gx) * p.ldn + ch * 8);   // < 2^31 elements (checked)
-          dv[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8(src, chn - ch * 8, p.vec_n);
+          dv[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8_raw(src, chn - ch * 8, p.vec_n);
         }
       }
     }
@@ -1394,20 +1405,23 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
         gv[it] = make_uint4(0, 0, 0, 0);
         if (row < HV && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
           const bf16_t* src = xb + (unsigned)(((gz * p.H + gy) * p.W + gx) * p.ldc + ch * 8);
-          gv[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8(src, chc - ch * 8, p.vec_c);
+          gv[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8_raw(src, chc - ch * 8, p.vec_c);
         }
       }
     }
   };
+  // (every piece of a thread has the same channel chunk: one mask per operand, applied when the piece goes to LDS)
+  const uint4 dmask = mask8(VEC ? 8 : chn - ch * 8), gmask = mask8(VEC ? 8 : chc - ch * 8);
+  auto and4 = [](uint4 v, uint4 m) { v.x &= m.x; v.y &= m.y; v.z &= m.z; v.w &= m.w; return v; };
   auto store_tile = [&]() {
     if (dlive) {
 #pragma unroll
-      for (int it = 0; it < DIT; ++it) reinterpret_cast<uint4*>(Dt)[tid + 256 * it] = dv[it];
+      for (int it = 0; it < DIT; ++it) reinterpret_cast<uint4*>(Dt)[tid + 256 * it] = VEC ? dv[it] : and4(dv[it], dmask);
     }
     if (glive) {
 #pragma unroll
       for (int it = 0; it < GIT; ++it)
-        if (tid + 256 * it < NGP) reinterpret_cast<uint4*>(Gt)[tid + 256 * it] = gv[it];
+        if (tid + 256 * it < NGP) reinterpret_cast<uint4*>(Gt)[tid + 256 * it] = VEC ? gv[it] : and4(gv[it], gmask);
     }
   };
 
