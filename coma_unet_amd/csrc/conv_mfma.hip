@@ -520,13 +520,17 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
                       (unsigned)(xb0 + h_x[it]) < (unsigned)p.W;
       hreg[it] = make_uint4(0, 0, 0, 0);
       if (VEC) { if (ok) hreg[it] = *reinterpret_cast<const uint4*>(xb + org + h_roff[it]); }
-      else if (ok && c0 + h_ch[it] < p.C) hreg[it] = load8(xb + org + h_roff[it], p.C - c0 - h_ch[it], p.vecx);
+      else if (ok && c0 + h_ch[it] < p.C) hreg[it] = load8_raw(xb + org + h_roff[it], p.C - c0 - h_ch[it], p.vecx);   // mask: at the LDS store
     }
   };
-  auto store_halo = [&]() {
+  auto store_halo = [&](int c0) {
 #pragma unroll
     for (int it = 0; it < HIT; ++it)
-      if (tid + 256 * it < HP) *reinterpret_cast<uint4*>(Hl + h_lds[it]) = hreg[it];
+      if (tid + 256 * it < HP) {
+        uint4 v = hreg[it];
+        if (!VEC) { const uint4 m = mask8(p.C - c0 - h_ch[it]); v.x &= m.x; v.y &= m.y; v.z &= m.z; v.w &= m.w; }
+        *reinterpret_cast<uint4*>(Hl + h_lds[it]) = v;
+      }
   };
   auto load_w = [&](int c0, int g) {     // RESIDENT: all 27 taps (g ignored); else kz-plane g
 #pragma unroll
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
 
     for (int cc = 0; cc < nchunks; ++cc) {
       __syncthreads();                       // all waves finished reading the previous halo / weights
-      store_halo();
+      store_halo(cc * CK);
       if (RESIDENT) {
         __syncthreads();
         if (has_next) load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0);
