@@ -565,9 +565,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
     }
     return;
   }
-  if (RESIDENT) { load_w(0, 0); store_w(); }
+  if (RESIDENT == 1) { load_w(0, 0); store_w(); }
   load_halo(tiz * TZ, tiy * TY, tix * TX, 0);
-  if (!RESIDENT) load_w(0, 0);
+  if (RESIDENT != 1) load_w(0, 0);
 
   const bool has_bias = p.bias != nullptr, do_stats = p.stats != nullptr;
   float bv[4][4];
@@ -600,8 +600,12 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
       __syncthreads();                       // all waves finished reading the previous halo / weights
       store_halo(cc * CK);
       if (RESIDENT) {
+        if (RESIDENT == 2) store_w();        // this chunk's 27 taps (fetched while the previous chunk / tile was computed)
         __syncthreads();
-        if (has_next) load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0);
+        if (RESIDENT == 2) {                 // next chunk of this tile, or chunk 0 of the next tile: a whole chunk of MFMAs to land
+          if (cc + 1 < nchunks) { load_w(cc * CK + CK, 0); load_halo(z0, y0, x0, cc * CK + CK); }
+          else if (has_next) { load_w(0, 0); load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0); }
+        } else if (has_next) load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0);
         // LDS fragments are read one tap ahead into a second register set (hipcc otherwise issues each ds_read right
         // before the MFMA that consumes it and waits lgkmcnt(0): the full LDS latency on every MFMA at 1-2 waves/SIMD)
         uint4 wv[2][KS], xv[2][2][KS];
@@ -967,17 +971,20 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     }
     constexpr int HV2 = 34 * 6 * 4;
     const bool resident = thin || q.C == 32;
-    const size_t lds = thin ? (size_t)(HV2 + 27 * 32) * 48 : (size_t)HV2 * 80 + (size_t)(resident ? 27 : 9) * 32 * 80;
+    // C >= 64: all 27 taps of the current 32-channel chunk in LDS, refetched per chunk (RESIDENT = 2).  The 9-taps-per-
+    // kz-plane streaming mode (RESIDENT = 0) it replaces left one plane of MFMAs (~0.5 us) to cover each weight fetch and
+    // cost 14 barriers per tile: 64 -> 32 at 128^3 940 -> 832 us, 128 -> 64 at 64^3 384 -> 328 us, 256 -> 128 at 32^3 186 -> 157 us.
+    const size_t lds = thin ? (size_t)(HV2 + 27 * 32) * 48 : (size_t)HV2 * 80 + (size_t)27 * 32 * 80;
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<1, 32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<0, 32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<2, 32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<1, 16, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       attr = true;
     }
     if (thin) hipLaunchKernelGGL((conv_mfma_halo2_k<1, 16, 0, 2>), grid, dim3(256), lds, s, q);
     else if (resident) hipLaunchKernelGGL((conv_mfma_halo2_k<1, 32, 1, 1>), grid, dim3(256), lds, s, q);
-    else hipLaunchKernelGGL((conv_mfma_halo2_k<0, 32, 1, 1>), grid, dim3(256), lds, s, q);
+    else hipLaunchKernelGGL((conv_mfma_halo2_k<2, 32, 1, 1>), grid, dim3(256), lds, s, q);
     COMA_LAUNCH_CHECK();
     return 0;
   }
