@@ -427,3 +427,39 @@ def test_routing_matches_torch(B, NC, E, N):
     Wr.grad = None
     (torch.sigmoid(torch.nn.functional.linear(cov, Wr, br)) * gr).sum().backward()
     assert float((g3 - Wr.grad).abs().max()) <= 1e-5 * max(1.0, float(Wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout", [(1, 32), (2, 8), (3, 16), (8, 1), (16, 3)])
+def test_thin_conv_on_padded_pitch_buffers_masks_foreign_lanes(cin, cout):
+    """The model keeps 1..3-channel volumes in buffers with an 8-channel pitch (ops._new); the MFMA staging then reads
+    16-byte pieces and must mask the lanes that are not the tensor's channels.  Here those lanes hold NaN: forward,
+    data-gradient and weight-gradient have to come out finite and equal to the fp64 reference."""
+    ops, L = _ops()
+    B, dims, k = 2, (6, 9, 37), 3
+    g = torch.Generator().manual_seed(cin * 10 + cout)
+    x = torch.randn((B, cin, *dims), generator=g).bfloat16().double()
+    w = (torch.randn((cout, cin, k, k, k), generator=g) * 0.2).bfloat16().float()
+    gy = torch.randn((B, cout, *dims), generator=g).bfloat16().double()
+    xr, wr = x.clone().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, padding=1)
+    yr.backward(gy)
+
+    def padded(t_ext):                      # (B,C,D,H,W) -> internal view with pitch 8 whose foreign lanes are NaN
+        v = to_int(t_ext).to("cuda", torch.bfloat16)
+        C = v.shape[-1]
+        if C % 8 == 0:
+            return v
+        buf = torch.full(tuple(v.shape[:4]) + ((C + 7) // 8 * 8,), float("nan"), dtype=torch.bfloat16, device="cuda")
+        buf[..., :C] = v
+        return buf[..., :C]
+
+    xi = padded(x).requires_grad_(True)
+    mg = w.cuda().requires_grad_(True)
+    a_f, a_d = ops.pick_algo(xi.shape, xi.dtype, cout, k, 1, False, False, xi.device, 0)
+    assert a_f == 2, "expected the MFMA path for this shape"
+    wd = lambda a: torch.bfloat16 if a == 2 else torch.float32
+    y = ops.ConvLayer.apply(xi, mg, None, None, k, 1, False, 0, None, None, wd(a_f), wd(a_d), True)
+    assert torch.isfinite(y.float()).all() and rel(to_ext(y), yr) < 8e-3
+    y.backward(padded(gy))
+    assert torch.isfinite(xi.grad.float()).all() and rel(to_ext(xi.grad), xr.grad) < 8e-3
+    assert torch.isfinite(mg.grad).all() and rel(mg.grad, wr.grad) < 8e-3
