@@ -1597,9 +1597,9 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   p.m_hxy = (unsigned)((1ull << 32) / (unsigned)(p.hx * p.hy)) + 1u;
   p.cblocks = (p.C + 32 * pl.tc - 1) / (32 * pl.tc);
   const int pairs = ((p.N + 32 * pl.tn - 1) / (32 * pl.tn)) * p.cblocks;
-  // one block per CU: aim for ~512 blocks, but never split the voxels further than needed to fill the chip --
-  // every extra chunk costs a full 27 x n x c fp32 atomic merge (~1.3 TB/s chip-wide)
-  int chunks = 512 / (pairs * x->B);
+  // one block per CU, ONE round (256 blocks): a second round repeats every block's 27 x n x c fp32 atomic merge
+  // (32 -> 64 stride 2 at 128^3: 307 -> 254 us; 256 -> 256 at 16^3: 163 -> 107 us)
+  int chunks = 256 / (pairs * x->B);
   // Deepest layers (>= 64 weight tiles, <= 1024 voxels): ONE block per tile and sample.  With per-sample weights (or one sample) every
   // dwk element then has a single producer: plain stores instead of memset + fp32 atomics (512 -> 512 at 8^3: the
   // 28 M atomics of a 2-chunk split cost ~90 of the kernel's 142 us).
