@@ -94,13 +94,19 @@ __global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double2* partial
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { sh[tid][2 * j] = s[j]; sh[tid][2 * j + 1] = q[j]; }
   __syncthreads();
-  if (ty == 0 && tx < p.cv) {
-    for (int y = 1; y < p.ry; ++y)
+  // rows of the block -> one: a tree over ty (ry = 256 / cvp is a power of two).  The serial walk this replaces cost
+  // ry x 2 VEC LDS reads on cv threads -- a fifth of the kernel on the 16-channel volumes (ry = 128).
+  for (int off = p.ry >> 1; off > 0; off >>= 1) {
+    if (ty < off) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { s[j] += sh[y * p.cvp + tx][2 * j]; q[j] += sh[y * p.cvp + tx][2 * j + 1]; }
+      for (int j = 0; j < 2 * VEC; ++j) sh[tid][j] += sh[tid + off * p.cvp][j];
+    }
+    __syncthreads();
+  }
+  if (ty == 0 && tx < p.cv) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-      partial[((int64_t)blockIdx.x * p.G + g) * p.C + tx * VEC + j] = make_double2(s[j], q[j]);
+      partial[((int64_t)blockIdx.x * p.G + g) * p.C + tx * VEC + j] = make_double2(sh[tid][2 * j], sh[tid][2 * j + 1]);
   }
 }
 
@@ -239,16 +245,18 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { sh[tid][3 * j] = s1[j]; sh[tid][3 * j + 1] = s2[j]; sh[tid][3 * j + 2] = s3[j]; }
   __syncthreads();
-  if (ty == 0 && tx < p.cv) {
-    for (int y = 1; y < p.ry; ++y)
+  for (int off = p.ry >> 1; off > 0; off >>= 1) {        // tree over the block's rows (see stats_partial_k)
+    if (ty < off) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        s1[j] += sh[y * p.cvp + tx][3 * j]; s2[j] += sh[y * p.cvp + tx][3 * j + 1]; s3[j] += sh[y * p.cvp + tx][3 * j + 2];
-      }
+      for (int j = 0; j < 3 * VEC; ++j) sh[tid][j] += sh[tid + off * p.cvp][j];
+    }
+    __syncthreads();
+  }
+  if (ty == 0 && tx < p.cv) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       double* o = partial + (((int64_t)blockIdx.x * p.G + g) * p.C + tx * VEC + j) * 3;
-      o[0] = s1[j]; o[1] = s2[j]; o[2] = s3[j];
+      o[0] = sh[tid][3 * j]; o[1] = sh[tid][3 * j + 1]; o[2] = sh[tid][3 * j + 2];
     }
   }
 }
