@@ -776,6 +776,7 @@ __global__ __launch_bounds__(256) void conv_mfma_pw_k(PwP p) {
         bv[j][g4][q] = (p.bias && nn < p.N) ? p.bias[b * p.bsb + nn] : 0.f;
       }
   }
+  const bool do_stats = p.stats != nullptr;
   float st_s[NT][4][4], st_q[NT][4][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -806,12 +807,15 @@ __global__ __launch_bounds__(256) void conv_mfma_pw_k(PwP p) {
         bf16_t* dst = yb + v * p.ldy + j * 32 + 4 * fh;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
+          if (j * 32 + 8 * g4 >= p.N) continue;          // (wave-uniform) zero-padded channel groups: nothing to convert or sum
           bf16_t o[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             o[q] = static_cast<bf16_t>(acc[g4 * 4 + q] + bv[j][g4][q]);
-            const float r = static_cast<float>(o[q]);
-            st_s[j][g4][q] += r; st_q[j][g4][q] = fmaf(r, r, st_q[j][g4][q]);
+            if (do_stats) {
+              const float r = static_cast<float>(o[q]);
+              st_s[j][g4][q] += r; st_q[j][g4][q] = fmaf(r, r, st_q[j][g4][q]);
+            }
           }
           if (p.st8 && j * 32 + 8 * g4 + 4 * fh + 3 < p.N) *reinterpret_cast<uint2*>(dst + 8 * g4) = *reinterpret_cast<uint2*>(o);
           else {
