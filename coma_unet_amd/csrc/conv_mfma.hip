@@ -455,6 +455,7 @@ struct Halo2P {
   int flip, vecx, vecw;
   int ntx, nty, ntz, ids_total, ids_per_block;
   int st8;             // output rows allow aligned 8-byte (4-channel) stores
+  int st16;            // ... and aligned 16-byte (8-channel) stores
   double2* stats;      // optional: per-block {sum, sumsq} of the stored outputs, [chunk][G][N]
   int stats_inst;      // 1: groups = samples (InstanceNorm), 0: one group (BatchNorm)
 };
@@ -675,7 +676,32 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
     for (int i = 0; i < 2; ++i) {
       const int j = wid * 2 + i;
       const int gz = z0 + (j >> 2), gy = y0 + (j & 3), gx = x0 + fr;
-      if (gz < p.D && gy < p.H && gx < p.W) {
+      if (OCC == 1 && p.st16 && n0 + 32 <= p.N) {
+        // Full 32-channel tiles: the two half-waves exchange 4-channel groups (v_permlane32_swap), so that every lane
+        // owns 8 CONSECUTIVE channels of its voxel and writes them with one 16-byte store (lanes fh = 0: channels
+        // 16 gp + 0..7, fh = 1: 16 gp + 8..15) instead of four 8-byte stores that each cover a quarter of a 64-byte row.
+        const bool valid = gz < p.D && gy < p.H && gx < p.W;
+        unsigned pk[4][2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          bf16_t o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o[q] = static_cast<bf16_t>(acc[i][g4 * 4 + q] + bv[g4][q]);
+            const float r = valid ? static_cast<float>(o[q]) : 0.f;
+            st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]);
+          }
+          const uint2 u = *reinterpret_cast<const uint2*>(o);
+          pk[g4][0] = u.x; pk[g4][1] = u.y;
+        }
+        bf16_t* vox = yb + ((long)(gz * p.H + gy) * p.W + gx) * p.ldy + n0 + 8 * fh;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
+          if (valid) *reinterpret_cast<uint4*>(vox + 16 * gp) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+      } else if (gz < p.D && gy < p.H && gx < p.W) {
         bf16_t* dst = yb + ((long)(gz * p.H + gy) * p.W + gx) * p.ldy + n0 + 4 * fh;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -960,6 +986,7 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     q.flip = p.flip; q.vecx = p.vecx; q.vecw = p.vecw;
     q.stats = nullptr; q.stats_inst = stats_inst;
     q.st8 = y->ld % 4 == 0 && y->sb % 4 == 0 && (((uintptr_t)y->data) & 7) == 0;
+    q.st16 = y->ld % 8 == 0 && y->sb % 8 == 0 && (((uintptr_t)y->data) & 15) == 0;
     q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
     q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
     const int nblk_n = (q.N + 31) / 32;
