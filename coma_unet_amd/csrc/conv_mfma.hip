@@ -701,6 +701,35 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
           const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
           if (valid) *reinterpret_cast<uint4*>(vox + 16 * gp) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
+      } else if (OCC == 2 && p.st16 && n0 + 16 <= p.N && ((p.N - n0) & 15) == 0) {
+        // thin variant, 16 (or 32) output channels: the same exchange, one 16-byte store per lane and 16 channels
+        const bool valid = gz < p.D && gy < p.H && gx < p.W;
+        bf16_t* vox = yb + ((long)(gz * p.H + gy) * p.W + gx) * p.ldy + n0 + 8 * fh;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          if (n0 + 16 * gp >= p.N) continue;            // (wave-uniform)
+          unsigned pk[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int g4 = 2 * gp + h;
+            bf16_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float a = acc[i][g4 * 4 + q];
+              if (has_bias) a += bv[g4][q];
+              o[q] = static_cast<bf16_t>(a);
+              if (do_stats) {
+                const float r = valid ? static_cast<float>(o[q]) : 0.f;
+                st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]);
+              }
+            }
+            const uint2 u = *reinterpret_cast<const uint2*>(o);
+            pk[h][0] = u.x; pk[h][1] = u.y;
+          }
+          const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+          if (valid) *reinterpret_cast<uint4*>(vox + 16 * gp) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
       } else if (gz < p.D && gy < p.H && gx < p.W) {
         bf16_t* dst = yb + ((long)(gz * p.H + gy) * p.W + gx) * p.ldy + n0 + 4 * fh;
 #pragma unroll
