@@ -138,13 +138,25 @@ def stream() -> int:
 
 
 _WS = {}
+_WS_PINNED = set()      # devices whose scratch buffer's address is baked into a captured hipGraph
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Stream-ordered scratch buffer (grown on demand, one per device)."""
+    """Stream-ordered scratch buffer (grown on demand, one per device).  While a captured graph holds the buffer's
+    raw pointer in its kernel arguments (pin_workspace) the cached buffer is never replaced: a larger request gets a
+    one-off allocation instead, so replays keep writing into memory that is still theirs."""
     key = (device.index if device.index is not None else torch.cuda.current_device())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _WS[key] = buf
+        new = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if buf is not None and key in _WS_PINNED:
+            return new
+        _WS[key] = buf = new
     return buf
+
+
+def pin_workspace(device) -> torch.Tensor:
+    """Called by a graph capture: returns the current scratch buffer (the caller keeps the reference alive)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    _WS_PINNED.add(key)
+    return workspace(1, device)

@@ -6,7 +6,16 @@ One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).  E
 holds a full replica with identical initial weights (broadcast once), runs forward /
 backward on its own samples, and the flat gradient buffer of ``FusedAdamW`` is SUM-reduced
 in contiguous buckets.  SUM, not mean: the reference reduces the per-sample loss vector with
-``torch.sum`` (criterions.py:560), so a global batch's gradient is the sum of the replicas'.
+``torch.sum`` (criterions.py:560), so for the per-sample generative term (RoiMSE) a global
+batch's gradient is the sum of the replicas'.  The RnC term (criterions.py:607-644) couples the
+samples of a batch and is evaluated PER REPLICA on its local samples: at the
+reference's 2 volumes per device it is identically zero (one off-diagonal logit), so under
+N-GPU data parallelism at B=2 it contributes nothing, whereas one device holding all 2N samples would
+train it (and so would an applied ``nn.DataParallel``, which gathers the outputs and evaluates the loss
+on device 0).  ``gather_batch`` below is the opt-in remedy: an autograd-aware all-gather of the (B, 512)
+features and (B, 6) labels, so that every rank evaluates RnC on the global batch and backward hands each
+rank the gradient of its own rows (``forward_loss(..., global_rnc=True)``; eager steps only).  Default off,
+as SURVEY.md section 8(e) prescribes; stated in DESIGN.md section 5.
 
 Overlap: each bucket's all-reduce is issued from a post-accumulate-grad hook as soon as the
 last gradient of that bucket has been produced by backward; RCCL runs it on the process
@@ -20,6 +29,34 @@ from __future__ import annotations
 
 import torch
 import torch.distributed as dist
+
+
+class _GatherBatch(torch.autograd.Function):
+    """cat over ranks along dim 0; backward: this rank's rows of the gradient (every rank evaluates the same
+    function of the gathered tensor, so the per-rank gradients of it are identical and need no exchange)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        world = dist.get_world_size(group)
+        ctx.rank = dist.get_rank(group)
+        ctx.rows = x.shape[0]
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x.contiguous(), group=group)
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.rank * ctx.rows:(ctx.rank + 1) * ctx.rows], None
+
+
+def gather_batch(x, group=None):
+    """(B, ...) per rank -> (world*B, ...) on every rank, differentiable.  Every rank then computes the SAME global
+    loss term T(F); rank r's backward sees dT/dF[rows of r], and the data-parallel SUM of the parameter gradients
+    over ranks assembles sum_r dT/dF_r dF_r/dtheta = dT/dtheta, the single-device gradient (weight 1, no rescale)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return x
+    return _GatherBatch.apply(x, group)
 
 
 def broadcast_module(module, src=0, group=None):

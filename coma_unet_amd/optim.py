@@ -52,6 +52,16 @@ class FusedAdamW(torch.optim.Optimizer):
             off += k
         self._flat_params = ps
         self._flat_ids = {id(p) for p in ps}
+        # a state_dict loaded BEFORE the layout existed (the reference's resume order: fresh optimizer ->
+        # load_state_dict -> train, validation.py:276-281, attn_unet_data_parallel.py:729-733) parked its moments in
+        # self.state[p]: move them into the flat buffers and carry the step count over
+        for p in ps:
+            st = self.state.pop(p, None)
+            if st:
+                off, k = self._offsets[id(p)]
+                self.flat_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.flat_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                self._flat_step = max(self._flat_step, int(st["step"]))
         self._step_dev = torch.full((1,), self._flat_step, dtype=torch.int32, device=dev)
 
     @property
@@ -119,8 +129,8 @@ class FusedAdamW(torch.optim.Optimizer):
         for k, v in sd["param_groups"][0].items():
             if k != "params":
                 self.param_groups[0][k] = v
-        self._pending_state = sd["state"]
-        # moments are applied lazily: the flat layout exists only after the first backward
+        # the flat layout exists only after the first backward: until then the moments wait in self.state[p]
+        # (per-parameter AdamW entries) and _build() moves them into the flat buffers
         for i, st in sd["state"].items():
             p = params[int(i)]
             if self.built and id(p) in self._flat_ids:
@@ -132,3 +142,5 @@ class FusedAdamW(torch.optim.Optimizer):
             else:
                 self.state[p] = {"step": int(st["step"]), "exp_avg": st["exp_avg"].to(p.device).float().clone(),
                                  "exp_avg_sq": st["exp_avg_sq"].to(p.device).float().clone()}
+        if self.built:      # parameters inside the flat buffer share one step count
+            self._step_dev.fill_(self._flat_step)

@@ -18,24 +18,34 @@ def make_optimizer(model, lr=1e-3, write_through=True):
     return FusedAdamW(model.parameters(), lr=lr, dynamic=dyn, write_through=write_through)
 
 
-def forward_loss(model, criterion, batch):
-    """Returns (total, gen_loss_vec, weighted_pred_contra, weighted_ds_contra), model_outputs."""
+def forward_loss(model, criterion, batch, global_rnc=False):
+    """Returns (total, gen_loss_vec, weighted_pred_contra, weighted_ds_contra), model_outputs.
+    global_rnc: under data parallelism evaluate the RnC term on the features / labels of ALL ranks
+    (data_parallel.gather_batch) instead of per replica -- see data_parallel's module docstring."""
     mri, tau, roi, covars = batch["mri"], batch["tau"], batch["roi"], batch["covars"]
     outs = model(mri, covars.to(device=mri.device), roi_pred_dicts=batch["roi_pred_dicts"], sample_roi_mask=roi)
     pred, projected, final_repr = outs[0], outs[1], outs[2]
     feats = torch.vstack([projected[-1]])                                   # :842
     labels = torch.vstack([covars[:, -1].to(device=mri.device)])            # :843
+    if global_rnc:
+        from .data_parallel import gather_batch
+        feats, labels = gather_batch(feats), gather_batch(labels.float())
     pos = torch.zeros_like(final_repr)                                      # :855 (fp16 zeros upstream)
     neg = torch.zeros_like(final_repr)                                      # :856
     losses = criterion(pred, tau, roi, (final_repr, pos, neg), (feats, labels))
     return losses, outs
 
 
-def train_step(model, criterion, optimizer, batch, reducer: GradReducer = None):
+def train_step(model, criterion, optimizer, batch, reducer: GradReducer = None, global_rnc=False):
+    if reducer is not None and reducer.world > 1:
+        # every rank must reduce the same tensors in the same order: with rank-local prompt selection the two
+        # selectable prompts get grad=None on some ranks only (attn_unet_data_parallel.py:638-639) and the collective
+        # sequences diverge (hang, or pos paired with neg)
+        assert getattr(model, "static_prompts", False), "data parallel steps need a model built with static_prompts=True"
     optimizer.zero_grad()                                                   # :806
     if reducer is not None:
         reducer.reset()
-    losses, outs = forward_loss(model, criterion, batch)
+    losses, outs = forward_loss(model, criterion, batch, global_rnc)
     losses[0].backward()                                                    # :884
     if reducer is not None:
         reducer.finish()
@@ -68,6 +78,8 @@ class GraphedTrainStep:
             for _ in range(max(warmup, 2)):      # builds the flat optimizer layout, sizes workspaces
                 train_step(model, criterion, optimizer, self.batch, reducer)
         torch.cuda.current_stream().wait_stream(side)
+        from ._lib import pin_workspace
+        self._ws = pin_workspace(self.batch["mri"].device)     # the graph bakes this buffer's address in: keep it alive and in place
         self._capture()
 
     def _hyper(self):

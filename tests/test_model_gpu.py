@@ -368,6 +368,59 @@ def test_checkpoint_roundtrip_and_plateau_scheduler(tmp_path):
     assert all(torch.equal(p, before[n]) for n, p in gm3.named_parameters())
 
 
+def test_resume_into_fresh_optimizer_matches_uninterrupted_run(tmp_path):
+    """The reference's resume order (validation.py:276-281, attn_unet_data_parallel.py:729-733): build a FRESH model and
+    optimizer, load_state_dict both, then train.  The first resumed step must equal step N+1 of the uninterrupted run:
+    Adam moments and the step count (bias correction) have to survive a load that happens before the flat layout exists.
+    Also loads a stock torch.optim.AdamW state_dict the same way."""
+    import coma_unet_amd as cu
+    from coma_unet_amd import checkpoint
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, make_optimizer
+    S = (32, 32, 32)
+    b = make_batch(2, S, seed=43)
+
+    def fresh(seed):
+        torch.manual_seed(seed)
+        gm = cu.build_model(volume_shape=S, static_prompts=True).cuda()
+        gm.set_save_attn(None)
+        gm.train(True)
+        gb = _gpu_batch(b)
+        gb["roi_pred_dicts"] = gm._priors(b["roi_pred_dicts"], 2, torch.device("cuda"))
+        return gm, gb, make_optimizer(gm, 1e-3)
+
+    crit = cu.build_reference_criterion()
+    gm, gb, opt = fresh(6)
+    for _ in range(3):
+        loss = train_step(gm, crit, opt, gb)[0][0]
+    files = checkpoint.save_checkpoint(str(tmp_path), 3, gm, opt, loss, None, checkpoint_iter=5)
+    sd_opt = opt.state_dict()
+    m_norm = float(opt.flat_m.norm())
+    l4 = float(train_step(gm, crit, opt, gb)[0][0])                      # step 4, uninterrupted
+    after4 = {n: p.detach().clone() for n, p in gm.named_parameters()}
+
+    gm2, gb2, opt2 = fresh(99)                                           # different init: everything must come from the file
+    checkpoint.load_checkpoint(files[0], gm2, opt2, None)                # BEFORE any step: no flat layout yet
+    assert not opt2.built
+    l4b = float(train_step(gm2, crit, opt2, gb2)[0][0])
+    assert opt2.built and opt2._flat_step == 4 and int(opt2._step_dev) == 4
+    assert not any(opt2.state[p] for p in opt2._flat_params if p in opt2.state)      # no dead fp32 clones left behind
+    assert abs(l4b - l4) <= 1e-3 * abs(l4)
+    worst = max(rel(p, after4[n]) for n, p in gm2.named_parameters() if float(after4[n].abs().max()) > 0)
+    assert worst < 5e-3, worst      # with zeroed moments / step = 1 the first Adam step is ~lr everywhere: > 1e-1 on small tensors
+    assert abs(float(opt2.state_dict()["state"][0]["step"]) - 4.0) == 0
+
+    # a stock torch.optim.AdamW state_dict (same param order) loads into a fresh FusedAdamW the same way
+    gm3, gb3, opt3 = fresh(6)
+    ref_opt = torch.optim.AdamW(gm3.parameters(), 1e-3)
+    ref_opt.load_state_dict(sd_opt)
+    opt3.load_state_dict(ref_opt.state_dict())
+    train_step(gm3, crit, opt3, gb3)
+    assert opt3._flat_step == 4
+    # moments after one more step: m4 = b1 m3 + (1-b1) g, so |m4| stays within a factor of the saved |m3| (not ~ (1-b1)|g| of a cold start)
+    assert float(opt3.flat_m.norm()) > 0.5 * m_norm
+
+
 def test_noncubic_volume_odd_batch():
     """Shapes the tiling has to cope with beyond the cubes of the BASELINE configs: a 32 x 48 x 64 volume, batch 3 --
     fp32 forward + loss against the oracle, then bf16 eager and graph-replayed train steps (finite, decreasing)."""
