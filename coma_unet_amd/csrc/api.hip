@@ -28,6 +28,7 @@ int conv_point1_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_
 int colsum(const coma_tensor* x, int per_sample, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 // conv_mfma.hip
 bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
+bool conv_f32mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                   const coma_tensor* y, hipStream_t s, double2* stats = nullptr, int stats_inst = 0,
                   int* stats_chunks = nullptr, void* ws = nullptr, size_t ws_bytes = 0);
@@ -42,11 +43,14 @@ int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_te
 
 extern "C" int coma_conv_pick_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (d->algo == 1) return 1;
-  return conv_mfma_supported(d, x, y) ? 2 : 1;   // algo 2 = "MFMA wherever the shape allows"
+  if (conv_point1_ok(d, x, y)) return 1;            // one channel on a side: streaming dot / scale kernels (fp32 weights)
+  if (conv_mfma_supported(d, x, y)) return 2;       // bf16 tensors: MFMA wherever the shape allows
+  if (conv_f32mfma_supported(d, x, y)) return 3;    // fp32 tensors: fp32 MFMA wherever the shape allows
+  return 1;
 }
 
 extern "C" size_t coma_conv_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
-  return coma_conv_pick_algo(d, x, y) == 2 ? conv_mfma_fwd_ws_bytes(d, x, y) : 0;
+  return coma_conv_pick_algo(d, x, y) >= 2 ? conv_mfma_fwd_ws_bytes(d, x, y) : 0;
 }
 
 extern "C" int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
@@ -66,14 +70,16 @@ extern "C" int coma_conv_fwd_ws(const coma_conv_desc* d, const coma_tensor* x, c
                x->C, y->C, x->dtype);
     return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes);
   }
-  COMA_CHECK(wk_dtype == COMA_F32, "conv_fwd: direct path needs fp32 kernel-layout weights");
+  COMA_CHECK(wk_dtype == COMA_F32, "conv_fwd: fp32 tensors need fp32 kernel-layout weights");
+  if (algo == 3) return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes);
   if (conv_point1_ok(d, x, y)) return conv_point1_fwd(d, x, (const float*)wk, bias, y, s);
   return conv_direct_fwd(d, x, (const float*)wk, bias, y, s);
 }
 
 extern "C" int coma_conv_wgrad_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   if (d->algo == 1 || conv_point1_ok(d, x, dy)) return 1;
-  return (x->dtype == COMA_BF16 && conv_mfma_wgrad_supported(d, x, dy)) ? 2 : 1;
+  if (!conv_mfma_wgrad_supported(d, x, dy)) return 1;
+  return x->dtype == COMA_BF16 ? 2 : 3;
 }
 
 // conv forward + the statistics of the following BatchNorm(train)/InstanceNorm in one pass where the kernel
@@ -85,7 +91,8 @@ extern "C" int coma_conv_fwd_norm_stats(const coma_conv_desc* d, const coma_tens
   if (int rc = conv_check(d, x, y)) return rc;
   COMA_CHECK(wk && mean && rstd && ws && ws_bytes >= coma_norm_ws_bytes(y), "conv_fwd_norm_stats: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  if (coma_conv_pick_algo(d, x, y) == 2 && wk_dtype == COMA_BF16) {
+  const int algo_ = coma_conv_pick_algo(d, x, y);
+  if ((algo_ == 2 && wk_dtype == COMA_BF16) || (algo_ == 3 && wk_dtype == COMA_F32)) {
     int chunks = 0;
     const int inst = mode == COMA_NORM_INSTANCE;
     if (int rc = conv_mfma_fwd(d, x, wk, bias, y, s, (double2*)ws, inst, &chunks, ws, ws_bytes)) return rc;
@@ -118,9 +125,6 @@ extern "C" int coma_conv_wgrad(const coma_conv_desc* d, const coma_tensor* x, co
   }
   if (conv_point1_ok(d, x, dy)) return conv_point1_wgrad(d, x, dy, dwk, s);
   const int algo = coma_conv_wgrad_algo(d, x, dy);
-  if (algo == 2) {
-    COMA_CHECK(conv_mfma_wgrad_supported(d, x, dy), "conv_wgrad: shape not supported by the MFMA path");
-    return conv_mfma_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
-  }
+  if (algo >= 2) return conv_mfma_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
   return conv_direct_wgrad(d, x, dy, dwk, s);
 }

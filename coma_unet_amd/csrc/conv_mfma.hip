@@ -14,10 +14,31 @@
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one MFMA A/B fragment
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 accumulator fragment
 
+// ---- element type of the activations / kernel-layout weights: bf16 (v_mfma_f32_32x32x16_bf16) or fp32
+// (v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation, 1/16 of the bf16 rate -- the "fp32 mode" of the model,
+// north_star's 1e-3 tolerance path).  Both use the SAME LDS images: a row is 64 bytes = 4 pieces of 16 bytes
+// (32 bf16 or 16 fp32 channels), and the 16-byte fragment a lane reads feeds one bf16 MFMA (K = 16: lane half h holds
+// k = 8h..8h+7) or four fp32 MFMAs (K = 2 each: MFMA m takes channel 4h + m of the piece from lane half h, so the
+// K pair of MFMA m is {m, 4 + m} of the 8 channels the two halves read -- the same for both operands).
+template <typename T> struct elem;
+template <> struct elem<bf16_t> { static constexpr int EPB = 8; };    // elements per 16-byte piece
+template <> struct elem<float> { static constexpr int EPB = 4; };
+
+__device__ __forceinline__ f32x16_t mma_piece(const uint4& a, const uint4& b, f32x16_t acc, bf16_t) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&a), *reinterpret_cast<const bf16x8_t*>(&b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16_t mma_piece(const uint4& a, const uint4& b, f32x16_t acc, float) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  return acc;
+}
+
 struct GatherP {
-  const bf16_t* x; int ldx; long sbx; int Di, Hi, Wi, C;
-  bf16_t* y; int ldy; long sby; int Do, Ho, Wo, N;
-  const bf16_t* w; long wsb;          // [b][tap][N][C]
+  const void* x; int ldx; long sbx; int Di, Hi, Wi, C;
+  void* y; int ldy; long sby; int Do, Ho, Wo, N;
+  const void* w; long wsb;          // [b][tap][N][C]
   const float* bias; int bsb;
   int k, stride, flip;
   int Mz, My, Mx;                      // M-grid (MODE 0: output grid; MODE 1: coarse grid)
@@ -50,8 +71,9 @@ __device__ __forceinline__ bool tile_coords(int id, int ntx, int nty, int ntz, i
 
 // MODE 0: in = m*stride - pad + tap  (all taps; `flip` mirrors the weight tap index)
 // MODE 1: stride-2 transposed gather, one output-parity class per blockIdx.y slice
-template <int BN, int MODE>
+template <int BN, int MODE, typename T = bf16_t>
 __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
+  constexpr int EPB = elem<T>::EPB, CKL = 4 * EPB, LCK = EPB == 8 ? 5 : 4;   // channels per K step (one 64-byte row) and its log2
   constexpr int BM = (BN == 128) ? 128 : 256;
   constexpr int WAVES_N = (BN == 128) ? 2 : 1;
   constexpr int NT = BN / 32 / WAVES_N;           // N-tiles per wave
@@ -73,8 +95,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
   const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
   const long Mtot = (long)p.Mz * p.My * p.Mx;
   const long m0 = (long)blockIdx.x * BM;
-  const bf16_t* xb = p.x + (long)b * p.sbx;
-  const bf16_t* wb = p.w + (long)b * p.wsb;
+  const T* xb = static_cast<const T*>(p.x) + (long)b * p.sbx;
+  const T* wb = static_cast<const T*>(p.w) + (long)b * p.wsb;
   const int pad = (p.k - 1) >> 1;
 
   // ---- per-thread gather rows (fixed over the K loop) ----
@@ -104,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
   }
 
   // ---- K loop bookkeeping ----
-  const int cchunks = p.C >> 5;
+  const int cchunks = p.C >> LCK;
   int ntaps;
   if (MODE == 0) ntaps = p.k * p.k * p.k; else ntaps = (1 + pz) * (1 + py) * (1 + px);
   const int nsteps_all = ntaps * cchunks;
@@ -132,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
       dx = px ? (jx ? 0 : 1) : 0; dy = py ? (jy ? 0 : 1) : 0; dz = pz ? (jz ? 0 : 1) : 0;
       wtap = (tz * 3 + ty) * 3 + tx;
     }
-    const int c0 = (cc << 5) + (chunk << 3);
+    const int c0 = cc * CKL + chunk * EPB;
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i) {
       const int iz = rz[i] + dz, iy = ry[i] + dy, ix = rx[i] + dx;
@@ -183,22 +205,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
     const uint4* B = ldsB + cur * BN * 4;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[MT], bfr[NT];
+      uint4 af[MT], bfr[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const uint4 v = A[swz(wm * 64 + i * 32 + fr, ks * 2 + fh)];
-        af[i] = *reinterpret_cast<const bf16x8_t*>(&v);
-      }
+      for (int i = 0; i < MT; ++i) af[i] = A[swz(wm * 64 + i * 32 + fr, ks * 2 + fh)];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const uint4 v = B[swz(wn * (NT * 32) + j * 32 + fr, ks * 2 + fh)];
-        bfr[j] = *reinterpret_cast<const bf16x8_t*>(&v);
-      }
+      for (int j = 0; j < NT; ++j) bfr[j] = B[swz(wn * (NT * 32) + j * 32 + fr, ks * 2 + fh)];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = mma_piece(af[i], bfr[j], acc[i][j], T());
     }
     if (step + 1 < nsteps) store_step(cur ^ 1);
     __syncthreads();
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
   }
 
   // ---- epilogue: + bias, cast, store (row = voxel, lane column = channel) ----
-  bf16_t* yb = p.y + (long)b * p.sby;
+  T* yb = static_cast<T*>(p.y) + (long)b * p.sby;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + wn * (NT * 32) + j * 32 + fr;
@@ -219,21 +234,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
         const int off = rowoff[row];
         if (off >= 0) {
           if (p.ksplit > 1) atomicAdd(p.part + (long)b * p.part_sb + (long)(off / p.ldy) * p.N + n, acc[i][j][e]);
-          else yb[off + n] = static_cast<bf16_t>(acc[i][j][e] + bv);
+          else yb[off + n] = static_cast<T>(acc[i][j][e] + bv);
         }
       }
     }
   }
 }
 
-// y[v][n] = bf16(part[v][n] + bias[n])  (the merge of the split-K partials)
-__global__ __launch_bounds__(256) void gather_finalize_k(const float* __restrict__ part, long part_sb, bf16_t* __restrict__ y, int ldy,
+// y[v][n] = T(part[v][n] + bias[n])  (the merge of the split-K partials)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_finalize_k(const float* __restrict__ part, long part_sb, T* __restrict__ y, int ldy,
                                                          long sby, int N, long V, const float* __restrict__ bias, int bsb) {
   const int b = blockIdx.y;
   const long total = V * N;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long v = e / N; const int n = (int)(e - v * N);
-    y[(long)b * sby + v * ldy + n] = static_cast<bf16_t>(part[(long)b * part_sb + e] + (bias ? bias[b * bsb + n] : 0.f));
+    y[(long)b * sby + v * ldy + n] = static_cast<T>(part[(long)b * part_sb + e] + (bias ? bias[b * bsb + n] : 0.f));
   }
 }
 
@@ -278,27 +294,30 @@ __device__ __forceinline__ uint4 mask8(int nvalid) {
 // bank-conflict free; ~70 KB LDS => 2 blocks (8 waves) per CU overlap staging with MFMA.
 // =====================================================================================
 struct HaloP {
-  const bf16_t* x; int ldx; long sbx; int D, H, W, C;
-  bf16_t* y; int ldy; long sby; int N;
-  const bf16_t* w; long wsb;
+  const void* x; int ldx; long sbx; int D, H, W, C;
+  void* y; int ldy; long sby; int N;
+  const void* w; long wsb;
   const float* bias; int bsb;
   int flip, vecx, vecw;
   int ntx, nty, ntz;
 };
 
-template <int CK> __device__ __forceinline__ int hswz(int row, int chunk) {
-  // 16-byte slot index of (row, chunk) in a [rows][CK] bf16 image
-  if (CK == 32) return (row << 2) | (chunk ^ ((row >> 2) & 3));
+template <int CPR> __device__ __forceinline__ int hswz(int row, int chunk) {
+  // 16-byte slot index of (row, chunk) in a [rows][CPR pieces] image
+  if (CPR == 4) return (row << 2) | (chunk ^ ((row >> 2) & 3));
   return (row << 1) | (chunk ^ ((row >> 3) & 1));
 }
 
-template <int CK, int LX, int VEC>   // VEC=1: every 8-channel piece is a legal, fully valid 16-byte load
+// CK = channels per LDS row (bf16: 32, or 16 for the thin layers; fp32: 16)
+template <int CK, int LX, int VEC, typename T = bf16_t>   // VEC=1: every piece is a legal, fully valid 16-byte load
 __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
+  constexpr int EPB = elem<T>::EPB;
+  static_assert(EPB == 8 || VEC == 1, "fp32 staging is vector-only");
   constexpr int TX = 1 << LX, RY = 32 / TX;      // M-tile = RY rows of TX voxels
   constexpr int TY = 4 * RY, TZ = 2;
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
-  constexpr int CPR = CK / 8;                     // 16-byte chunks per row
-  constexpr int KS = CK / 16;                     // MFMA K steps per tap
+  constexpr int CPR = CK / EPB;                   // 16-byte chunks per row
+  constexpr int KS = CPR / 2;                     // fragment reads (16-byte pieces per lane half) per tap
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* Hl = reinterpret_cast<uint4*>(smem);                  // halo  [HV][CPR]
   uint4* Wl = Hl + HV * CPR;                                   // weights [9][32][CPR]
@@ -307,8 +326,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
   int tix, tiy, tiz;
   if (!tile_coords(xcd_remap(blockIdx.x, gridDim.x), p.ntx, p.nty, p.ntz, tix, tiy, tiz)) return;
   const int x0 = tix * TX, y0 = tiy * TY, z0 = tiz * TZ;
-  const bf16_t* xb = p.x + (long)b * p.sbx;
-  const bf16_t* wb = p.w + (long)b * p.wsb;
+  const T* xb = static_cast<const T*>(p.x) + (long)b * p.sbx;
+  const T* wb = static_cast<const T*>(p.w) + (long)b * p.wsb;
   const int fr = lane & 31, fh = lane >> 5;
 
   f32x16_t acc[2];
@@ -330,6 +349,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
   constexpr int HP = HV * CPR, HIT = (HP + 255) / 256;          // halo pieces, per-thread iterations
   constexpr int WP = 9 * 32 * CPR, WIT = (WP + 255) / 256;      // weight pieces of one kz-plane
   uint4 hreg[HIT], wreg[WIT];
+  auto ld_piece = [&](const T* src, int nvalid, int vecok) -> uint4 {
+    if constexpr (VEC) return *reinterpret_cast<const uint4*>(src);
+    else return load8(reinterpret_cast<const bf16_t*>(src), nvalid, vecok);
+  };
   auto load_halo = [&](int c0) {
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
@@ -337,21 +360,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
       const int row = piece / CPR, ch = piece % CPR;
       const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
       const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-      const int cbeg = c0 + ch * 8;
+      const int cbeg = c0 + ch * EPB;
       hreg[it] = make_uint4(0, 0, 0, 0);
       if (piece < HP && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W &&
           cbeg < p.C)
-      {
-        const bf16_t* src = xb + (long)((gz * p.H + gy) * p.W + gx) * p.ldx + cbeg;
-        hreg[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8(src, p.C - cbeg, p.vecx);
-      }
+        hreg[it] = ld_piece(xb + (long)((gz * p.H + gy) * p.W + gx) * p.ldx + cbeg, p.C - cbeg, p.vecx);
     }
   };
   auto store_halo = [&]() {
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
       const int piece = tid + 256 * it;
-      if (piece < HP) Hl[hswz<CK>(piece / CPR, piece % CPR)] = hreg[it];
+      if (piece < HP) Hl[hswz<CPR>(piece / CPR, piece % CPR)] = hreg[it];
     }
   };
   auto load_w = [&](int c0, int g) {
@@ -361,20 +381,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
       const int ch = piece % CPR, n = (piece / CPR) & 31, t9 = piece / (CPR * 32);
       const int gt = g * 9 + t9;
       const int wt = p.flip ? 26 - gt : gt;
-      const int cbeg = c0 + ch * 8;
+      const int cbeg = c0 + ch * EPB;
       wreg[it] = make_uint4(0, 0, 0, 0);
       if (piece < WP && n0 + n < p.N && cbeg < p.C)
-      {
-        const bf16_t* src = wb + ((long)wt * p.N + n0 + n) * p.C + cbeg;
-        wreg[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8(src, p.C - cbeg, p.vecw);
-      }
+        wreg[it] = ld_piece(wb + ((long)wt * p.N + n0 + n) * p.C + cbeg, p.C - cbeg, p.vecw);
     }
   };
   auto store_w = [&]() {
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
       const int piece = tid + 256 * it;
-      if (piece < WP) Wl[hswz<CK>((piece / (CPR * 32)) * 32 + ((piece / CPR) & 31), piece % CPR)] = wreg[it];
+      if (piece < WP) Wl[hswz<CPR>((piece / (CPR * 32)) * 32 + ((piece / CPR) & 31), piece % CPR)] = wreg[it];
     }
   };
 
@@ -400,12 +417,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
           const int toff = (g * HY + dy) * HX + dx;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const uint4 bv = Wl[hswz<CK>(t9 * 32 + fr, ks * 2 + fh)];
-            const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(&bv);
+            const uint4 bv = Wl[hswz<CPR>(t9 * 32 + fr, ks * 2 + fh)];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              const uint4 av = Hl[hswz<CK>(hbase[i] + toff, ks * 2 + fh)];
-              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&av), bf, acc[i], 0, 0, 0);
+              const uint4 av = Hl[hswz<CPR>(hbase[i] + toff, ks * 2 + fh)];
+              acc[i] = mma_piece(av, bv, acc[i], T());
             }
           }
         }
@@ -416,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
   const int n = n0 + fr;
   if (n < p.N) {
     const float bv = p.bias ? p.bias[b * p.bsb + n] : 0.f;
-    bf16_t* yb = p.y + (long)b * p.sby;
+    T* yb = static_cast<T*>(p.y) + (long)b * p.sby;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int j = wid * 2 + i;
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
         const int gy = y0 + (j & 3) * RY + (row >> LX), gx = x0 + (row & (TX - 1));
         if (gz < p.D && gy < p.H && gx < p.W)
-          yb[(long)((gz * p.H + gy) * p.W + gx) * p.ldy + n] = static_cast<bf16_t>(acc[i][e] + bv);
+          yb[(long)((gz * p.H + gy) * p.W + gx) * p.ldy + n] = static_cast<T>(acc[i][e] + bv);
       }
     }
   }
@@ -448,9 +464,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
 // cycles waiting; this structure brings the instruction mix under 2 VALU per MFMA.
 // =====================================================================================
 struct Halo2P {
-  const bf16_t* x; int ldx; long sbx; int D, H, W, C;
-  bf16_t* y; int ldy; long sby; int N;
-  const bf16_t* w; long wsb;
+  const void* x; int ldx; long sbx; int D, H, W, C;
+  void* y; int ldy; long sby; int N;
+  const void* w; long wsb;
   const float* bias; int bsb;
   int flip, vecx, vecw;
   int ntx, nty, ntz, ids_total, ids_per_block;
@@ -460,13 +476,16 @@ struct Halo2P {
   int stats_inst;      // 1: groups = samples (InstanceNorm), 0: one group (BatchNorm)
 };
 
-// CK = channels per LDS row (32, or 16 for the thin full-resolution layers: one MFMA K step per tap);
-// VEC = every 8-channel piece is a legal, fully valid 16-byte load; OCC = blocks per CU.
-template <int RESIDENT, int CK, int VEC, int OCC>
+// CK = channels per LDS row (bf16: 32, or 16 for the thin full-resolution layers: one MFMA K step per tap; fp32: 16);
+// VEC = every piece is a legal, fully valid 16-byte load; OCC = blocks per CU; T = element type (see `elem`).
+template <int RESIDENT, int CK, int VEC, int OCC, typename T = bf16_t>
 __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
+  constexpr int EPB = elem<T>::EPB;
+  constexpr bool F32 = EPB == 4;
+  static_assert(!F32 || (VEC == 1 && OCC == 1 && RESIDENT == 2), "fp32: vector staging, one block per CU, per-chunk weights");
   constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
-  constexpr int CPR = CK / 8, KS = CK / 16;          // 16-byte pieces per row, MFMA K steps per tap
-  constexpr int P = CK == 32 ? 80 : 48;               // LDS row pitch (bytes): 16 rows land on 16 distinct 16-B slots
+  constexpr int CPR = CK / EPB, KS = CPR / 2;        // 16-byte pieces per row, fragment reads per tap and operand
+  constexpr int P = CPR == 4 ? 80 : 48;               // LDS row pitch (bytes): 16 rows land on 16 distinct 16-B slots
   constexpr int HP = HV * CPR, HIT = (HP + 255) / 256;  // halo pieces, per-thread iterations
   constexpr int WT = RESIDENT ? 27 : 9;               // taps held in LDS at once
   constexpr int WP = WT * 32 * CPR, WIT = (WP + 255) / 256;
@@ -476,9 +495,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.z, n0 = blockIdx.y * 32;
   const int fr = lane & 31, fh = lane >> 5;
-  const bf16_t* xb = p.x + (long)b * p.sbx;
-  const bf16_t* wb = p.w + (long)b * p.wsb;
-  bf16_t* yb = p.y + (long)b * p.sby;
+  const T* xb = static_cast<const T*>(p.x) + (long)b * p.sbx;
+  const T* wb = static_cast<const T*>(p.w) + (long)b * p.wsb;
+  T* yb = static_cast<T*>(p.y) + (long)b * p.sby;
   const int nchunks = (p.C + CK - 1) / CK;
 
   // ---- staging descriptors (tile independent) ----
@@ -489,8 +508,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
     const int row = piece / CPR, ch = piece % CPR;
     const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
     h_z[it] = piece < HP ? hz : (1 << 20); h_y[it] = hy; h_x[it] = hx;
-    h_ch[it] = ch * 8;
-    h_roff[it] = ((hz * p.H + hy) * p.W + hx) * p.ldx + ch * 8;
+    h_ch[it] = ch * EPB;
+    h_roff[it] = ((hz * p.H + hy) * p.W + hx) * p.ldx + ch * EPB;
     h_lds[it] = row * P + ch * 16;
   }
   int w_goff[WIT], w_lds[WIT], w_ch[WIT];
@@ -498,8 +517,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   for (int it = 0; it < WIT; ++it) {
     const int piece = tid + 256 * it;
     const int ch = piece % CPR, n = (piece / CPR) & 31, t = piece / (CPR * 32);     // t: tap within the LDS image
-    w_ch[it] = ch * 8;
-    w_goff[it] = (piece < WP && n0 + n < p.N) ? (n0 + n) * p.C + ch * 8 : -1;   // + wtap*N*C + c0 at load time
+    w_ch[it] = ch * EPB;
+    w_goff[it] = (piece < WP && n0 + n < p.N) ? (n0 + n) * p.C + ch * EPB : -1;   // + wtap*N*C + c0 at load time
     w_lds[it] = (t * 32 + n) * P + ch * 16;
   }
   // fragment read bases
@@ -520,8 +539,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
       const bool ok = (unsigned)(zb + h_z[it]) < (unsigned)p.D && (unsigned)(yb0 + h_y[it]) < (unsigned)p.H &&
                       (unsigned)(xb0 + h_x[it]) < (unsigned)p.W;
       hreg[it] = make_uint4(0, 0, 0, 0);
-      if (VEC) { if (ok) hreg[it] = *reinterpret_cast<const uint4*>(xb + org + h_roff[it]); }
-      else if (ok && c0 + h_ch[it] < p.C) hreg[it] = load8_raw(xb + org + h_roff[it], p.C - c0 - h_ch[it], p.vecx);   // mask: at the LDS store
+      if constexpr (VEC) { if (ok) hreg[it] = *reinterpret_cast<const uint4*>(xb + org + h_roff[it]); }
+      else if (ok && c0 + h_ch[it] < p.C) hreg[it] = load8_raw(reinterpret_cast<const bf16_t*>(xb + org + h_roff[it]), p.C - c0 - h_ch[it], p.vecx);   // mask: at the LDS store
     }
   };
   auto store_halo = [&](int c0) {
@@ -540,9 +559,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
       const int t = piece / (CPR * 32) + (RESIDENT ? 0 : g * 9);
       const int wt = p.flip ? 26 - t : t;
       wreg[it] = make_uint4(0, 0, 0, 0);
-      if (VEC) { if (w_goff[it] >= 0) wreg[it] = *reinterpret_cast<const uint4*>(wb + (long)wt * p.N * p.C + c0 + w_goff[it]); }
+      if constexpr (VEC) { if (w_goff[it] >= 0) wreg[it] = *reinterpret_cast<const uint4*>(wb + (long)wt * p.N * p.C + c0 + w_goff[it]); }
       else if (w_goff[it] >= 0 && c0 + w_ch[it] < p.C)
-        wreg[it] = load8(wb + (long)wt * p.N * p.C + c0 + w_goff[it], p.C - c0 - w_ch[it], p.vecw);
+        wreg[it] = load8(reinterpret_cast<const bf16_t*>(wb + (long)wt * p.N * p.C + c0 + w_goff[it]), p.C - c0 - w_ch[it], p.vecw);
     }
   };
   auto store_w = [&]() {
@@ -629,9 +648,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wv[t & 1][ks]),
-                                                               *reinterpret_cast<const bf16x8_t*>(&xv[t & 1][i][ks]),
-                                                               (OCC == 2 && t == 0 && ks == 0) ? zero : acc[i], 0, 0, 0);
+              acc[i] = mma_piece(wv[t & 1][ks], xv[t & 1][i][ks], (OCC == 2 && t == 0 && ks == 0) ? zero : acc[i], T());
             }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -663,9 +680,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-              for (int i = 0; i < 2; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wv[t & 1][ks]),
-                                                                 *reinterpret_cast<const bf16x8_t*>(&xv[t & 1][i][ks]), acc[i], 0, 0, 0);
+              for (int i = 0; i < 2; ++i) acc[i] = mma_piece(wv[t & 1][ks], xv[t & 1][i][ks], acc[i], T());
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -676,6 +691,28 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
     for (int i = 0; i < 2; ++i) {
       const int j = wid * 2 + i;
       const int gz = z0 + (j >> 2), gy = y0 + (j & 3), gx = x0 + fr;
+      if constexpr (F32) {
+        // fp32: the lane's 4 consecutive channels of a group are one 16-byte store as they stand
+        const bool valid = gz < p.D && gy < p.H && gx < p.W;
+        float* dst = reinterpret_cast<float*>(yb) + ((long)(gz * p.H + gy) * p.W + gx) * p.ldy + n0 + 4 * fh;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          if (n0 + 8 * g4 >= p.N) continue;            // (wave-uniform)
+          float o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o[q] = acc[i][g4 * 4 + q] + bv[g4][q];
+            if (do_stats) { const float r = valid ? o[q] : 0.f; st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]); }
+          }
+          if (valid) {
+            if (p.st16 && n0 + 8 * g4 + 4 * fh + 3 < p.N) *reinterpret_cast<float4*>(dst + 8 * g4) = make_float4(o[0], o[1], o[2], o[3]);
+            else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (n0 + 8 * g4 + 4 * fh + q < p.N) dst[8 * g4 + q] = o[q];
+            }
+          }
+        }
+      } else
       if (OCC == 1 && p.st16 && n0 + 32 <= p.N) {
         // Full 32-channel tiles: the two half-waves exchange 4-channel groups (v_permlane32_swap), so that every lane
         // owns 8 CONSECUTIVE channels of its voxel and writes them with one 16-byte store (lanes fh = 0: channels
@@ -937,8 +974,34 @@ bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const co
   return true;
 }
 
+// ---- fp32 mode (v_mfma_f32_32x32x2_f32): which problems the MFMA kernels take; the rest stays on conv_direct ----
+static bool f32_halo_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  if (x->W < 16 && x->C % 32 == 0 && y->C % 32 == 0) return false;       // 8^3 grids: gather + split-K (as bf16)
+  return d->ksize == 3 && d->stride == 1 && x->W >= 8 && (long)x->H * x->W >= 32 && x->C % 16 == 0 && y->C >= 16 &&
+         x->ld % 4 == 0 && x->sb % 4 == 0 && (!x->data || aligned16(x->data));
+}
+bool conv_f32mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  if (x->dtype != COMA_F32 || y->dtype != COMA_F32) return false;
+  if ((long)t_vox(x) * x->ld >= (1L << 31) || (long)t_vox(y) * y->ld >= (1L << 31)) return false;
+  if (f32_halo_ok(d, x, y)) return true;
+  if (x->C % 16 || y->C % 32) return false;
+  if (x->ld % 4 || y->ld % 4 || x->sb % 4 || y->sb % 4) return false;
+  if (x->data && !aligned16(x->data)) return false;
+  if (d->form == 1 && d->stride == 2 && d->ksize != 3) return false;
+  return true;
+}
+
 // split-K factor for a gather launch of `blocks` tiles and `nsteps` K steps (1 = no split)
-static int gather_ksplit(long blocks, int nsteps) {
+static int gather_ksplit(long blocks, int nsteps, bool f32 = false) {
+  // fp32 MFMA: a K step is 16x the MFMA time of a bf16 one, so the global-load latency per step is covered with one
+  // block per CU; split only to fill the chip
+  if (f32) {
+    if (blocks >= 192 || nsteps < 8) return 1;
+    long ks = 256 / blocks;
+    if (ks > 8) ks = 8;
+    if (ks > nsteps / 4) ks = nsteps / 4;
+    return ks < 2 ? 1 : (int)ks;
+  }
   // a block's K loop exposes one global-load latency per 32-channel step (8 MFMAs per wave): with one block per CU a
   // deep layer is latency-bound, so the split aims at ~4 resident blocks per CU, not merely at filling the CUs
   // (measured: more slices than this lose to their own atomic traffic -- every slice adds a full fp32 tile)
@@ -949,66 +1012,71 @@ static int gather_ksplit(long blocks, int nsteps) {
   return ks < 2 ? 1 : (int)ks;
 }
 
-template <int BN>
+template <int BN, typename T>
 static int launch_gather(const GatherP& p0, int mode, int B, hipStream_t s, void* ws, size_t ws_bytes) {
   GatherP p = p0;
   constexpr int BM = (BN == 128) ? 128 : 256;
+  constexpr int LCK = elem<T>::EPB == 8 ? 5 : 4;
   const long Mtot = (long)p.Mz * p.My * p.Mx;
   const size_t lds = (size_t)2 * (BM + BN) * 64 + BM * 4;
   const unsigned gx = (unsigned)((Mtot + BM - 1) / BM), gy = (unsigned)(p.N / BN) * (mode == 1 ? 8 : 1);
   const long Vout = (long)p.Do * p.Ho * p.Wo;
   const int ntaps_max = mode == 1 ? 8 : p.k * p.k * p.k;      // (mode 1: the 8-tap parity class bounds the split)
-  p.ksplit = gather_ksplit((long)gx * gy * B, (mode == 1 ? 1 : ntaps_max) * (p.C >> 5));
+  p.ksplit = gather_ksplit((long)gx * gy * B, (mode == 1 ? 1 : ntaps_max) * (p.C >> LCK), LCK == 4);
   p.part = nullptr; p.part_sb = 0;
   if (p.ksplit > 1 && ws && ws_bytes >= sizeof(float) * (size_t)B * Vout * p.N) {
     p.part = (float*)ws; p.part_sb = Vout * p.N;
     if (hipMemsetAsync(ws, 0, sizeof(float) * (size_t)B * Vout * p.N, s) != hipSuccess) { coma_set_error("conv split-K memset failed"); return 2; }
   } else p.ksplit = 1;
   dim3 grid(gx, gy * p.ksplit, (unsigned)B);
-  if (mode == 0) hipLaunchKernelGGL((conv_mfma_gather_k<BN, 0>), grid, dim3(256), lds, s, p);
-  else hipLaunchKernelGGL((conv_mfma_gather_k<BN, 1>), grid, dim3(256), lds, s, p);
+  if (mode == 0) hipLaunchKernelGGL((conv_mfma_gather_k<BN, 0, T>), grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL((conv_mfma_gather_k<BN, 1, T>), grid, dim3(256), lds, s, p);
   COMA_LAUNCH_CHECK();
   if (p.ksplit > 1) {
     long nb = (Vout * p.N + 255) / 256;
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(gather_finalize_k, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, (const float*)p.part, p.part_sb, p.y, p.ldy,
+    hipLaunchKernelGGL(gather_finalize_k<T>, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, (const float*)p.part, p.part_sb, (T*)p.y, p.ldy,
                        p.sby, p.N, Vout, p.bias, p.bsb);
     COMA_LAUNCH_CHECK();
   }
   return 0;
 }
 
-template <int CK, int LX, int VEC>
+template <int CK, int LX, int VEC, typename T>
 static int launch_halo(const HaloP& p0, int B, hipStream_t s) {
   HaloP p = p0;
   constexpr int TX = 1 << LX, RY = 32 / TX, TY = 4 * RY, TZ = 2;
   constexpr int HV = (TX + 2) * (TY + 2) * (TZ + 2);
   p.ntx = (p.W + TX - 1) / TX; p.nty = (p.H + TY - 1) / TY; p.ntz = (p.D + TZ - 1) / TZ;
-  const size_t lds = (size_t)(HV + 9 * 32) * CK * 2;
+  const size_t lds = (size_t)(HV + 9 * 32) * CK * sizeof(T);
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)conv_mfma_halo_k<CK, LX, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+  if (!attr) { (void)hipFuncSetAttribute((const void*)conv_mfma_halo_k<CK, LX, VEC, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
   dim3 grid((unsigned)(p.ntx * p.nty * ((p.ntz + 7) / 8) * 8), (unsigned)((p.N + 31) / 32), (unsigned)B);
-  hipLaunchKernelGGL((conv_mfma_halo_k<CK, LX, VEC>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((conv_mfma_halo_k<CK, LX, VEC, T>), grid, dim3(256), lds, s, p);
   COMA_LAUNCH_CHECK();
   return 0;
 }
 
 // stats != NULL requests fused {sum, sumsq} partials; *stats_chunks receives the number of chunks written, or stays
 // 0 when the selected kernel variant cannot fuse them (the caller then runs the stand-alone statistics pass).
+template <typename T>
 static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                           const coma_tensor* y, hipStream_t s, double2* stats = nullptr, int stats_inst = 0,
                           int* stats_chunks = nullptr) {
+  constexpr int EPB = elem<T>::EPB;
+  constexpr bool F32 = EPB == 4;
   HaloP p;
-  p.x = (const bf16_t*)x->data; p.ldx = (int)x->ld; p.sbx = x->sb; p.D = x->D; p.H = x->H; p.W = x->W; p.C = x->C;
-  p.y = (bf16_t*)y->data; p.ldy = (int)y->ld; p.sby = y->sb; p.N = y->C;
-  p.w = (const bf16_t*)wk; p.wsb = d->per_sample_w ? 27L * y->C * x->C : 0;
+  p.x = x->data; p.ldx = (int)x->ld; p.sbx = x->sb; p.D = x->D; p.H = x->H; p.W = x->W; p.C = x->C;
+  p.y = y->data; p.ldy = (int)y->ld; p.sby = y->sb; p.N = y->C;
+  p.w = wk; p.wsb = d->per_sample_w ? 27L * y->C * x->C : 0;
   p.bias = bias; p.bsb = d->per_sample_w ? y->C : 0;
   p.flip = d->form == 1;
-  p.vecx = x->ld % 8 == 0 && x->sb % 8 == 0 && aligned16(x->data);
-  p.vecw = x->C % 8 == 0 && aligned16(wk);
-  const bool thin = x->C <= 16;
+  p.vecx = x->ld % EPB == 0 && x->sb % EPB == 0 && aligned16(x->data);
+  p.vecw = x->C % EPB == 0 && aligned16(wk);
+  const bool thin = !F32 && x->C <= 16;
   const int lx = x->W >= 32 ? 5 : (x->W >= 16 ? 4 : 3);
-  const bool vec = p.vecx && p.vecw && x->C % 32 == 0;
+  const bool vec = p.vecx && p.vecw && x->C % (4 * EPB) == 0;
+  if (F32) COMA_CHECK(vec, "conv_mfma(fp32): operands must allow 16-byte channel pieces (C %% 16 == 0, aligned)");
   if (lx == 5 && (thin || vec)) {
     Halo2P q;
     q.x = p.x; q.ldx = p.ldx; q.sbx = p.sbx; q.D = p.D; q.H = p.H; q.W = p.W; q.C = p.C;
@@ -1016,11 +1084,12 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     q.flip = p.flip; q.vecx = p.vecx; q.vecw = p.vecw;
     q.stats = nullptr; q.stats_inst = stats_inst;
     q.st8 = y->ld % 4 == 0 && y->sb % 4 == 0 && (((uintptr_t)y->data) & 7) == 0;
-    q.st16 = y->ld % 8 == 0 && y->sb % 8 == 0 && (((uintptr_t)y->data) & 15) == 0;
+    q.st16 = y->ld % EPB == 0 && y->sb % EPB == 0 && (((uintptr_t)y->data) & 15) == 0;
     q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
     q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
     const int nblk_n = (q.N + 31) / 32;
     int gx = (thin ? 1024 : 512) / (nblk_n * x->B);   // thin: 2 blocks per CU, thick: 1
+    if (F32) gx = 256 / (nblk_n * x->B);               // fp32 tiles are 16x longer: one round of one block per CU balances best
     if (gx < 1) gx = 1;
     if (gx > q.ids_total) gx = q.ids_total;
     q.ids_per_block = (q.ids_total + gx - 1) / gx;
@@ -1031,50 +1100,67 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
       *stats_chunks = stats_inst ? gx : gx * x->B;
     }
     constexpr int HV2 = 34 * 6 * 4;
-    const bool resident = thin || q.C == 32;
+    const bool resident = thin || (!F32 && q.C == 32);
     // C >= 64: all 27 taps of the current 32-channel chunk in LDS, refetched per chunk (RESIDENT = 2).  The 9-taps-per-
     // kz-plane streaming mode (RESIDENT = 0) it replaces left one plane of MFMAs (~0.5 us) to cover each weight fetch and
     // cost 14 barriers per tile: 64 -> 32 at 128^3 940 -> 832 us, 128 -> 64 at 64^3 384 -> 328 us, 256 -> 128 at 32^3 186 -> 157 us.
     const size_t lds = thin ? (size_t)(HV2 + 27 * 32) * 48 : (size_t)HV2 * 80 + (size_t)27 * 32 * 80;
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<1, 32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<2, 32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<1, 16, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      if constexpr (F32) {
+        (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<2, 16, 1, 1, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      } else {
+        (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<1, 32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<2, 32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_mfma_halo2_k<1, 16, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      }
       attr = true;
     }
-    if (thin) hipLaunchKernelGGL((conv_mfma_halo2_k<1, 16, 0, 2>), grid, dim3(256), lds, s, q);
-    else if (resident) hipLaunchKernelGGL((conv_mfma_halo2_k<1, 32, 1, 1>), grid, dim3(256), lds, s, q);
-    else hipLaunchKernelGGL((conv_mfma_halo2_k<2, 32, 1, 1>), grid, dim3(256), lds, s, q);
+    if constexpr (F32) {
+      hipLaunchKernelGGL((conv_mfma_halo2_k<2, 16, 1, 1, float>), grid, dim3(256), lds, s, q);
+    } else {
+      if (thin) hipLaunchKernelGGL((conv_mfma_halo2_k<1, 16, 0, 2>), grid, dim3(256), lds, s, q);
+      else if (resident) hipLaunchKernelGGL((conv_mfma_halo2_k<1, 32, 1, 1>), grid, dim3(256), lds, s, q);
+      else hipLaunchKernelGGL((conv_mfma_halo2_k<2, 32, 1, 1>), grid, dim3(256), lds, s, q);
+    }
     COMA_LAUNCH_CHECK();
     return 0;
   }
-  if (thin) {
-    if (lx == 5) return launch_halo<16, 5, 0>(p, x->B, s);
-    if (lx == 4) return launch_halo<16, 4, 0>(p, x->B, s);
-    return launch_halo<16, 3, 0>(p, x->B, s);
+  if constexpr (F32) {
+    if (lx == 5) return launch_halo<16, 5, 1, float>(p, x->B, s);
+    if (lx == 4) return launch_halo<16, 4, 1, float>(p, x->B, s);
+    return launch_halo<16, 3, 1, float>(p, x->B, s);
+  } else {
+    if (thin) {
+      if (lx == 5) return launch_halo<16, 5, 0, bf16_t>(p, x->B, s);
+      if (lx == 4) return launch_halo<16, 4, 0, bf16_t>(p, x->B, s);
+      return launch_halo<16, 3, 0, bf16_t>(p, x->B, s);
+    }
+    if (vec) {
+      if (lx == 5) return launch_halo<32, 5, 1, bf16_t>(p, x->B, s);
+      if (lx == 4) return launch_halo<32, 4, 1, bf16_t>(p, x->B, s);
+      return launch_halo<32, 3, 1, bf16_t>(p, x->B, s);
+    }
+    if (lx == 5) return launch_halo<32, 5, 0, bf16_t>(p, x->B, s);
+    if (lx == 4) return launch_halo<32, 4, 0, bf16_t>(p, x->B, s);
+    return launch_halo<32, 3, 0, bf16_t>(p, x->B, s);
   }
-  if (vec) {
-    if (lx == 5) return launch_halo<32, 5, 1>(p, x->B, s);
-    if (lx == 4) return launch_halo<32, 4, 1>(p, x->B, s);
-    return launch_halo<32, 3, 1>(p, x->B, s);
-  }
-  if (lx == 5) return launch_halo<32, 5, 0>(p, x->B, s);
-  if (lx == 4) return launch_halo<32, 4, 0>(p, x->B, s);
-  return launch_halo<32, 3, 0>(p, x->B, s);
 }
 
 // bytes of workspace with which the deep layers' K loop may be split over more blocks (0: never split)
 size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
-  if (halo_ok(d, x, y) || pw_ok(d, x, y)) return 0;
+  if (x->dtype == COMA_F32) { if (f32_halo_ok(d, x, y)) return 0; }
+  else if (halo_ok(d, x, y) || pw_ok(d, x, y)) return 0;
   return sizeof(float) * (size_t)y->B * t_vox(y) * y->C <= ((size_t)64 << 20) ? sizeof(float) * (size_t)y->B * t_vox(y) * y->C : 0;
 }
 
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                   const coma_tensor* y, hipStream_t s, double2* stats, int stats_inst, int* stats_chunks, void* ws,
                   size_t ws_bytes) {
-  if (halo_ok(d, x, y)) return conv_mfma_halo(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
-  if (pw_ok(d, x, y) && !(x->C % 32 == 0 && y->C % 32 == 0 && x->C * y->C > 64 * 32)) {
+  const bool f32 = x->dtype == COMA_F32;
+  if (f32) { if (f32_halo_ok(d, x, y)) return conv_mfma_halo<float>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks); }
+  else if (halo_ok(d, x, y)) return conv_mfma_halo<bf16_t>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
+  if (!f32 && pw_ok(d, x, y) && !(x->C % 32 == 0 && y->C % 32 == 0 && x->C * y->C > 64 * 32)) {
     COMA_CHECK(aligned16(wk), "conv_mfma: weights must be 16-byte aligned");
     PwP q;
     q.x = (const bf16_t*)x->data; q.ldx = (int)x->ld; q.sbx = x->sb; q.V = t_vox(x); q.C = x->C;
@@ -1102,10 +1188,10 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
   }
   COMA_CHECK(aligned16(wk) && aligned16(x->data), "conv_mfma: operands must be 16-byte aligned");
   GatherP p;
-  p.x = (const bf16_t*)x->data; p.ldx = (int)x->ld; p.sbx = x->sb; p.Di = x->D; p.Hi = x->H; p.Wi = x->W; p.C = x->C;
-  p.y = (bf16_t*)y->data; p.ldy = (int)y->ld; p.sby = y->sb; p.Do = y->D; p.Ho = y->H; p.Wo = y->W; p.N = y->C;
+  p.x = x->data; p.ldx = (int)x->ld; p.sbx = x->sb; p.Di = x->D; p.Hi = x->H; p.Wi = x->W; p.C = x->C;
+  p.y = y->data; p.ldy = (int)y->ld; p.sby = y->sb; p.Do = y->D; p.Ho = y->H; p.Wo = y->W; p.N = y->C;
   const int taps = d->ksize * d->ksize * d->ksize;
-  p.w = (const bf16_t*)wk; p.wsb = d->per_sample_w ? (long)taps * y->C * x->C : 0;
+  p.w = wk; p.wsb = d->per_sample_w ? (long)taps * y->C * x->C : 0;
   p.bias = bias; p.bsb = d->per_sample_w ? y->C : 0;
   p.k = d->ksize; p.stride = d->stride; p.flip = 0;
   int mode = 0;
@@ -1116,9 +1202,14 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
   } else {
     p.Mz = y->D; p.My = y->H; p.Mx = y->W;
   }
-  if (y->C % 128 == 0) return launch_gather<128>(p, mode, x->B, s, ws, ws_bytes);
-  if (y->C % 64 == 0) return launch_gather<64>(p, mode, x->B, s, ws, ws_bytes);
-  return launch_gather<32>(p, mode, x->B, s, ws, ws_bytes);
+  if (f32) {
+    if (y->C % 128 == 0) return launch_gather<128, float>(p, mode, x->B, s, ws, ws_bytes);
+    if (y->C % 64 == 0) return launch_gather<64, float>(p, mode, x->B, s, ws, ws_bytes);
+    return launch_gather<32, float>(p, mode, x->B, s, ws, ws_bytes);
+  }
+  if (y->C % 128 == 0) return launch_gather<128, bf16_t>(p, mode, x->B, s, ws, ws_bytes);
+  if (y->C % 64 == 0) return launch_gather<64, bf16_t>(p, mode, x->B, s, ws, ws_bytes);
+  return launch_gather<32, bf16_t>(p, mode, x->B, s, ws, ws_bytes);
 }
 
 // =====================================================================================
@@ -1138,8 +1229,8 @@ typedef __attribute__((ext_vector_type(4))) short s4_t;
 typedef __attribute__((address_space(3))) s4_t lds_s4_t;
 
 struct WgradP2 {
-  const bf16_t* dyp; int ldn; long sbn;     // dy  (N channels)
-  const bf16_t* xp;  int ldc; long sbc;     // x   (C channels)
+  const void* dyp; int ldn; long sbn;     // dy  (N channels)
+  const void* xp;  int ldc; long sbc;     // x   (C channels)
   int N, C;
   int Mz, My, Mx;      // dense grid
   int Gz, Gy, Gx;      // gathered grid
@@ -1170,8 +1261,10 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
   const int b = blockIdx.z;
   const int nb = blockIdx.y / p.cblocks, cb = blockIdx.y % p.cblocks;
   const int n0 = nb * 32 * TN, c0 = cb * 32 * TC;
-  const bf16_t* dense = (FORM == 0 ? p.dyp + (long)b * p.sbn + n0 : p.xp + (long)b * p.sbc + c0);
-  const bf16_t* gath = (FORM == 0 ? p.xp + (long)b * p.sbc + c0 : p.dyp + (long)b * p.sbn + n0);
+  const bf16_t* dyp16 = static_cast<const bf16_t*>(p.dyp);
+  const bf16_t* xp16 = static_cast<const bf16_t*>(p.xp);
+  const bf16_t* dense = (FORM == 0 ? dyp16 + (long)b * p.sbn + n0 : xp16 + (long)b * p.sbc + c0);
+  const bf16_t* gath = (FORM == 0 ? xp16 + (long)b * p.sbc + c0 : dyp16 + (long)b * p.sbn + n0);
   const int ldd = FORM == 0 ? p.ldn : p.ldc, ldg = FORM == 0 ? p.ldc : p.ldn;
   const int chd = (FORM == 0 ? p.N - n0 : p.C - c0), chg = (FORM == 0 ? p.C - c0 : p.N - n0);   // channels left
   const bool vecd = FORM == 0 ? p.vec_n : p.vec_c, vecg = FORM == 0 ? p.vec_c : p.vec_n;
@@ -1322,6 +1415,160 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
               else atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, acc[t][i][j][e]);
             }
           }
+    }
+  }
+}
+
+// =====================================================================================
+// conv_f32_wgrad_k -- the weight gradient in fp32 mode on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
+// accumulation).  Same block structure as conv_mfma_wgrad_k (one 32 x 32 slab of dwk per block, dense tile + gathered
+// halo staged once in LDS as [voxel][32 channels] fp32 rows, the 27 taps dealt to the 4 waves, accumulators stationary
+// over the block's tiles), but the MFMA reduces over TWO voxels per instruction and takes one fp32 per lane and operand:
+// lane (channel = lane & 31, voxel = lane >> 5) reads its value with a plain ds_read_b32 -- 32 consecutive floats per
+// half-wave, conflict-free, no transposed reads.  An fp32 MFMA occupies the SIMD for 64 cycles, so the two LDS reads and
+// the address arithmetic per MFMA sit in its shadow; the next voxel pair's fragments are read one step ahead.
+// =====================================================================================
+template <int FORM>
+__global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
+  constexpr int PR = 128;                            // LDS row pitch (bytes): 32 fp32 channels
+  constexpr int MAXT = 7;                            // taps per wave
+  constexpr int MAXP = 34;                           // 16-byte staging pieces per thread (host guarantees the fit)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int TM = 1 << (p.lx + p.ly + p.lz);
+  char* Dt = smem;
+  char* Gt = smem + TM * PR;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int b = blockIdx.z;
+  const int nb = blockIdx.y / p.cblocks, cb = blockIdx.y % p.cblocks;
+  const int n0 = nb * 32, c0 = cb * 32;
+  const float* dyp = reinterpret_cast<const float*>(p.dyp);
+  const float* xp = reinterpret_cast<const float*>(p.xp);
+  const float* dense = (FORM == 0 ? dyp + (long)b * p.sbn + n0 : xp + (long)b * p.sbc + c0);
+  const float* gath = (FORM == 0 ? xp + (long)b * p.sbc + c0 : dyp + (long)b * p.sbn + n0);
+  const int ldd = FORM == 0 ? p.ldn : p.ldc, ldg = FORM == 0 ? p.ldc : p.ldn;
+  const int chd = (FORM == 0 ? p.N - n0 : p.C - c0), chg = (FORM == 0 ? p.C - c0 : p.N - n0);   // channels left
+  const int ntaps = p.k * p.k * p.k;
+  const int HV = p.hz * p.hy * p.hx;
+  const int tx = 1 << p.lx, ty = 1 << p.ly;
+
+  f32x16_t acc[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  int tap_w[MAXT], toff_w[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int tap = p.k == 1 ? (t == 0 ? 0 : ntaps) : wid + 4 * t;
+    tap_w[t] = tap;
+    const int kx = tap % p.k, ky = (tap / p.k) % p.k, kz = tap / (p.k * p.k);
+    toff_w[t] = __builtin_amdgcn_readfirstlane(((kz * p.hy + ky) * p.hx + kx) * PR);
+  }
+
+  const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * p.tiles_per_block;
+  int tile_end = tile_begin + p.tiles_per_block;
+  if (tile_end > p.tiles_total) tile_end = p.tiles_total;
+
+  // ---- staging: 16-byte pieces (4 channels), the next tile's loads in flight while this tile computes ----
+  uint4 sv[MAXP];
+  const int ndp = TM * 8, ngp = HV * 8;
+  auto load_tile = [&](int x0, int y0, int z0) {
+    const int bz = z0 * p.stride - p.pad, by = y0 * p.stride - p.pad, bx = x0 * p.stride - p.pad;
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+      const int piece = tid + 256 * u;
+      sv[u] = make_uint4(0, 0, 0, 0);
+      if (piece < ndp) {
+        const int row = piece >> 3, ch = piece & 7;
+        const int vx = row & (tx - 1), vy = (row >> p.lx) & (ty - 1), vz = row >> (p.lx + p.ly);
+        const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+        if (gz < p.Mz && gy < p.My && gx < p.Mx && ch * 4 < chd)
+          sv[u] = *reinterpret_cast<const uint4*>(dense + (unsigned)(((gz * p.My + gy) * p.Mx + gx) * ldd + ch * 4));
+      } else if (piece < ndp + ngp) {
+        const int pg = piece - ndp;
+        const int row = pg >> 3, ch = pg & 7;
+        const int q1 = (int)__umulhi((unsigned)row, p.m_hx), hzi = (int)__umulhi((unsigned)row, p.m_hxy);
+        const int hxi = row - q1 * p.hx, hyi = q1 - hzi * p.hy;
+        const int gz = bz + hzi, gy = by + hyi, gx = bx + hxi;
+        if ((unsigned)gz < (unsigned)p.Gz && (unsigned)gy < (unsigned)p.Gy && (unsigned)gx < (unsigned)p.Gx && ch * 4 < chg)
+          sv[u] = *reinterpret_cast<const uint4*>(gath + (unsigned)(((gz * p.Gy + gy) * p.Gx + gx) * ldg + ch * 4));
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+      const int piece = tid + 256 * u;
+      if (piece < ndp + ngp) reinterpret_cast<uint4*>(smem)[piece] = sv[u];     // dense rows, then halo rows: contiguous
+    }
+  };
+
+  // one voxel pair (2 q, 2 q + 1: x neighbours of one row) -> the lane's dense value and its taps' gathered values
+  const int lane_d = fh * PR + fr * 4, lane_g = fh * p.stride * PR + fr * 4;
+  auto rd = [&](int q, float& d, float (&g)[MAXT]) {
+    const int v = 2 * q;
+    const int x = v & (tx - 1), y = (v >> p.lx) & (ty - 1), z = v >> (p.lx + p.ly);
+    d = *reinterpret_cast<const float*>(Dt + v * PR + lane_d);
+    const char* gp = Gt + ((z * p.stride * p.hy + y * p.stride) * p.hx + x * p.stride) * PR + lane_g;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+      if (tap_w[t] < ntaps) g[t] = *reinterpret_cast<const float*>(gp + toff_w[t]);
+  };
+  auto mm = [&](float d, const float (&g)[MAXT]) {
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+      if (tap_w[t] < ntaps) {
+        if (FORM == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(d, g[t], acc[t], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t], d, acc[t], 0, 0, 0);
+      }
+  };
+
+  const int npairs = TM >> 1;
+  const int qs = p.k == 1 ? 4 : 1, q0 = p.k == 1 ? wid : 0;   // 1x1x1: the 4 waves share the single tap by voxel pair
+  int tile = tile_begin, tix = 0, tiy = 0, tiz = 0;
+  while (tile < tile_end && !tile_coords(tile, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++tile;
+  if (tile < tile_end) load_tile(tix << p.lx, tiy << p.ly, tiz << p.lz);
+  while (tile < tile_end) {
+    int nt = tile + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nt < tile_end && !tile_coords(nt, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nt;
+    __syncthreads();   // previous tile's reads are done
+    store_tile();
+    __syncthreads();
+    if (nt < tile_end) load_tile(ntix << p.lx, ntiy << p.ly, ntiz << p.lz);
+    float dA, dB, gA[MAXT], gB[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) { gA[t] = 0.f; gB[t] = 0.f; }
+    rd(q0, dA, gA);
+    for (int q = q0; q < npairs; q += 2 * qs) {          // (npairs is a multiple of 8)
+      rd(q + qs, dB, gB);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(dA, gA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 2 * qs < npairs) rd(q + 2 * qs, dA, gA);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(dB, gB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    tile = nt; tix = ntix; tiy = ntiy; tiz = ntiz;
+  }
+  // ---- merge into dwk[b][tap][n][c] ----
+  float* wout = p.dwk + (long)b * p.wsb;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int tap = tap_w[t];
+    if (tap < ntaps) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int c = c0 + fr;
+        if (n < p.N && c < p.C) {
+          if (p.plain) wout[((long)tap * p.N + n) * p.C + c] = acc[t][e];
+          else atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, acc[t][e]);
+        }
+      }
     }
   }
 }
@@ -1616,13 +1863,18 @@ struct WgradPlan { WgradP2 p; int TM; size_t lds; int tn, tc; dim3 grid; bool ok
 static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   WgradPlan pl{};
   pl.ok = false;
-  if (x->dtype != COMA_BF16 || dy->dtype != COMA_BF16) return pl;
+  const bool f32 = x->dtype == COMA_F32 && dy->dtype == COMA_F32;
+  if (!f32 && (x->dtype != COMA_BF16 || dy->dtype != COMA_BF16)) return pl;
+  if (f32) {   // fp32 kernel: 16-byte pieces of 4 channels, vector staging only; >= 16 channels a side (below that: conv_direct)
+    if (x->C % 4 || dy->C % 4 || x->C < 16 || dy->C < 16 || x->ld % 4 || dy->ld % 4 || x->sb % 4 || dy->sb % 4) return pl;
+    if ((x->data && !aligned16(x->data)) || (dy->data && !aligned16(dy->data))) return pl;
+  }
   if (d->ksize != 3 && d->ksize != 1) return pl;
   if ((long)t_vox(x) * x->ld >= (1L << 31) || (long)t_vox(dy) * dy->ld >= (1L << 31)) return pl;
   if (d->form == 1 && d->stride != 2) return pl;
   WgradP2& p = pl.p;
-  p.dyp = (const bf16_t*)dy->data; p.ldn = (int)dy->ld; p.sbn = dy->sb;
-  p.xp = (const bf16_t*)x->data; p.ldc = (int)x->ld; p.sbc = x->sb;
+  p.dyp = dy->data; p.ldn = (int)dy->ld; p.sbn = dy->sb;
+  p.xp = x->data; p.ldc = (int)x->ld; p.sbc = x->sb;
   p.N = dy->C; p.C = x->C;
   const coma_tensor* dn = d->form == 0 ? dy : x;     // dense
   const coma_tensor* ga = d->form == 0 ? x : dy;     // gathered
@@ -1632,6 +1884,8 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   p.vec_c = x->ld % 8 == 0 && x->sb % 8 == 0 && (!x->data || aligned16(x->data));
   pl.tn = (dy->C > 32 && !(x->C > 32 && x->C > dy->C)) ? 2 : 1;
   pl.tc = (pl.tn == 1 && x->C > 32) ? 2 : 1;
+  if (f32) pl.tn = pl.tc = 1;
+  const int esz = f32 ? 4 : 2, ppc = f32 ? 4 : 8, maxp = f32 ? 34 : 20;   // bytes per element, channels per piece, pieces per thread
   // tile: up to 256 dense voxels at stride 1, 64 at stride 2 (the halo grows 8x); shrink until the LDS image
   // and the per-thread register staging budget (20 x 16-byte pieces) fit
   const int cdb = 32 * (d->form == 0 ? pl.tn : pl.tc), cgb = 32 * (d->form == 0 ? pl.tc : pl.tn);
@@ -1648,8 +1902,8 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
     p.lx = lx; p.ly = ly; p.lz = lz;
     pl.TM = 1 << (lx + ly + lz);
     p.hz = ((1 << lz) - 1) * p.stride + p.k; p.hy = ((1 << ly) - 1) * p.stride + p.k; p.hx = ((1 << lx) - 1) * p.stride + p.k;
-    pl.lds = (size_t)pl.TM * cdb * 2 + (size_t)p.hz * p.hy * p.hx * cgb * 2;
-    fits = pl.lds <= 160 * 1024 && pl.TM * (cdb / 8) + p.hz * p.hy * p.hx * (cgb / 8) <= 256 * 20;
+    pl.lds = (size_t)pl.TM * cdb * esz + (size_t)p.hz * p.hy * p.hx * cgb * esz;
+    fits = pl.lds <= 160 * 1024 && pl.TM * (cdb / ppc) + p.hz * p.hy * p.hx * (cgb / ppc) <= 256 * maxp;
   }
   if (!fits) return pl;
   p.ntx = (p.Mx + (1 << p.lx) - 1) >> p.lx; p.nty = (p.My + (1 << p.ly) - 1) >> p.ly; p.ntz = (p.Mz + (1 << p.lz) - 1) >> p.lz;
@@ -1680,7 +1934,7 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
 }
 
 bool conv_mfma_wgrad_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
-  return wgrad2_ok(d, x, dy) || wgrad_plan(d, x, dy).ok;
+  return wgrad2_ok(d, x, dy) || wgrad_plan(d, x, dy).ok;      // (bf16 and fp32: the plan checks the dtype pair)
 }
 size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   const long wsz = wgrad_out_elems(d, x, dy);
@@ -1695,6 +1949,18 @@ int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_te
   pl.p.dwk = dwk;
   const long wsz = (long)d->ksize * d->ksize * d->ksize * dy->C * x->C * (d->per_sample_w ? x->B : 1);
   if (!pl.p.plain && hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  if (x->dtype == COMA_F32) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)conv_f32_wgrad_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_f32_wgrad_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    if (d->form == 0) hipLaunchKernelGGL((conv_f32_wgrad_k<0>), pl.grid, dim3(256), pl.lds, s, pl.p);
+    else hipLaunchKernelGGL((conv_f32_wgrad_k<1>), pl.grid, dim3(256), pl.lds, s, pl.p);
+    COMA_LAUNCH_CHECK();
+    return 0;
+  }
   const bool vecall = pl.p.vec_n && pl.p.vec_c && dy->C % 8 == 0 && x->C % 8 == 0;
 #define WL(TNV, TCV, F)                                                                                          \
   do {                                                                                                           \

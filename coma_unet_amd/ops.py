@@ -77,6 +77,9 @@ def conv_class(algo_name, cin, cout):
     return "mfma-thick" if min(cin, cout) >= 32 else "mfma-thin"
 
 
+_ALGO_NAMES = {1: "direct", 2: "mfma", 3: "mfma-f32"}
+
+
 def _new(shape, dtype, device):
     """Activation buffer.  (B, D, H, W, C) volumes whose channel count is not a multiple of 8 (the 1..3-channel tensors of
     the full-resolution tail) get a voxel pitch rounded up to 8 channels: every kernel takes the pitch `ld`, and 16-byte
@@ -255,10 +258,10 @@ def _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm):
     n = wk_f.shape[2]
     y = out.t if out is not None else _new((B, Do, Ho, Wo, n), x.dtype, x.device)
     b = bias.contiguous().float() if bias is not None else None
-    kind = conv_class("mfma" if wk_f.dtype == torch.bfloat16 else "direct", x.shape[4], n)
     d = _desc(ksize, stride, form, per_sample, algo)
     tag = (tuple(x.shape), n, ksize, stride, form)
     cx, cy = ct(x), ct(y)
+    kind = conv_class(_ALGO_NAMES[lib.coma_conv_pick_algo(d, cx, cy)] if KernelTimer.enabled else "", x.shape[4], n)
     if norm is None:
         ws = workspace(lib.coma_conv_fwd_ws_bytes(d, cx, cy), x.device)      # split-K scratch of the deep layers
         KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
@@ -289,7 +292,8 @@ def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_d
         dx = _new(x.shape, x.dtype, x.device)
         dd, cdy_, cdx = _desc(ksize, stride, 1 - form, per_sample, algo), ct(dy), ct(dx)
         wsd = workspace(lib.coma_conv_fwd_ws_bytes(dd, cdy_, cdx), x.device)
-        KernelTimer.run("conv_dgrad", conv_class("mfma" if wk_d.dtype == torch.bfloat16 else "direct", dy.shape[4], x.shape[4]),
+        KernelTimer.run("conv_dgrad", conv_class(_ALGO_NAMES[lib.coma_conv_pick_algo(dd, cdy_, cdx)] if KernelTimer.enabled else "",
+                                                   dy.shape[4], x.shape[4]),
                         conv_flops(dy.shape, dx.shape, ksize, stride),
                         lambda: check(lib.coma_conv_fwd_ws(dd, cdy_, ptr(wk_d), L.dtype_code(wk_d.dtype), None, cdx, ptr(wsd),
                                                            wsd.numel(), s), "coma_conv_fwd(dgrad)"), tag=tag)
@@ -307,7 +311,7 @@ def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_d
         elif bias_mode == 2 and not per_sample:   # (per-sample: the routing node receives None = zero)
             sink = GradSink.slot(p_bias)          # the flat gradient buffer was zeroed by zero_grad(): nothing to write
             dbias = None if sink is not None else torch.zeros(bshape, dtype=torch.float32, device=x.device)
-        walgo = conv_class("mfma" if lib.coma_conv_wgrad_algo(d, cx, cdy) == 2 else "direct", x.shape[4], dy.shape[4])
+        walgo = conv_class(_ALGO_NAMES[lib.coma_conv_wgrad_algo(d, cx, cdy)] if KernelTimer.enabled else "", x.shape[4], dy.shape[4])
         KernelTimer.run("conv_wgrad", walgo, conv_flops(x.shape, dy.shape, ksize, stride),
                         lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias_k), ptr(ws), ws.numel(), s),
                                       "coma_conv_wgrad"), tag=tag)

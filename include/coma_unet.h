@@ -71,8 +71,9 @@ typedef struct coma_conv_desc {
   int32_t pad;            /* 0 or 1 */
   int32_t form;           /* 0 conv, 1 tconv */
   int32_t per_sample_w;   /* 1: wk/bias have a leading B dim (CondConv) */
-  int32_t algo;           /* 0 auto, 1 force the direct VALU fp32 kernels, 2 MFMA wherever the shape allows
-                             (bf16 tensors only; unsupported shapes still take the direct kernels) */
+  int32_t algo;           /* 0 auto: MFMA wherever the shape allows (bf16 tensors: v_mfma_f32_32x32x16_bf16; fp32 tensors:
+                             v_mfma_f32_32x32x2_f32, exact fp32), otherwise the direct kernels;
+                             1 force the direct VALU fp32 kernels; 2 = 0 (kept for callers of ABI 1) */
 } coma_conv_desc;
 
 int         coma_abi_version(void);
@@ -109,8 +110,9 @@ int coma_routing_bwd(const float* cov, int32_t B, int32_t NC, const float* r, in
                      float* dWr, float* dbr, float* dbias_e, void* stream);
 
 /* ---- convolution (nn.Conv3d / nn.ConvTranspose3d and their data-gradients) ---- */
-/* which kernel family algo==0 resolves to for this problem: 1 direct (wants fp32 wk),
- * 2 MFMA (wants bf16 wk).  The host prepares the kernel-layout weights accordingly.   */
+/* which kernel family algo==0 resolves to for this problem: 1 direct (wants fp32 wk), 2 bf16 MFMA
+ * (wants bf16 wk), 3 fp32 MFMA (fp32 tensors, wants fp32 wk).  The host prepares the kernel-layout
+ * weights accordingly.  coma_conv_wgrad_algo answers the same question for the weight gradient.   */
 int coma_conv_pick_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
                   int32_t wk_dtype, const float* bias, const coma_tensor* y, void* stream);

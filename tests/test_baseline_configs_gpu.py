@@ -152,7 +152,7 @@ def test_c2_64cubed_batch4_bf16_voxel_l1():
     gm = _gpu_model(S, sd, torch.bfloat16)
     gb = _gpu_batch(b)
     outs = gm(gb["mri"], gb["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=gb["roi"])
-    lv = cu.VoxelL1()(outs[0], gb["tau"])
+    lv = cu.VoxelL1(reduction=None)(outs[0], gb["tau"])
     assert tuple(lv.shape) == (B, 1)
     lv.sum().backward()
     torch.cuda.synchronize()
@@ -168,7 +168,7 @@ def test_c2_64cubed_batch4_bf16_voxel_l1():
     # the same configuration in fp32 meets the fp32 bound (L1's sign gradient included)
     gm32 = _gpu_model(S, sd, torch.float32)
     o32 = gm32(gb["mri"], gb["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=gb["roi"])
-    l32 = cu.VoxelL1()(o32[0], gb["tau"])
+    l32 = cu.VoxelL1(reduction=None)(o32[0], gb["tau"])
     l32.sum().backward()
     assert rel(o32[0], out) <= 1e-3 and abs(float(l32.sum()) - total) / abs(total) <= 1e-4
     g32 = dict(gm32.named_parameters())

@@ -394,6 +394,72 @@ def test_conv_mfma_fwd_dgrad_wgrad(case, per_sample):
     assert rel(wk_f.grad, gw) < 5e-3
 
 
+F32_MFMA_CASES = MFMA_CASES + [
+    # fp32 mode also takes 16-channel inputs and 16-channel outputs on the halo kernels (16 channels = one 64-byte row)
+    (16, 16, 3, 1, False, (6, 5, 40)), (16, 32, 3, 1, False, (5, 9, 17)), (48, 16, 3, 1, False, (4, 6, 33)),
+    (16, 32, 3, 2, False, (8, 10, 12)), (64, 64, 3, 1, False, (9, 12, 64)), (128, 64, 3, 1, False, (3, 8, 8)),
+]
+
+
+@pytest.mark.parametrize("per_sample", [False, True])
+@pytest.mark.parametrize("case", F32_MFMA_CASES)
+def test_conv_f32_mfma_fwd_dgrad_wgrad(case, per_sample):
+    """fp32 mode: the same shapes on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation) against an fp64
+    reference; only the summation order differs from a CPU fp32 conv, so the bound is the fp32 one (2e-5)."""
+    ops, L = _ops()
+    cin, cout, k, s, tr, dims = case
+    B, E = 2, 3
+    g = torch.Generator().manual_seed(sum(dims) + cin + 1)
+    x = torch.randn((B, cin, *dims), generator=g).double()
+    wshape = (cin, cout, k, k, k) if tr else (cout, cin, k, k, k)
+    p = (k - 1) // 2
+    if per_sample:
+        master = torch.randn((E, *wshape), generator=g) * 0.1
+        r = torch.rand((B, E), generator=g)
+        wmix = torch.einsum("be,e...->b...", r.double(), master.double())
+        bias = torch.randn((B, cout), generator=g)
+    else:
+        master = torch.randn(wshape, generator=g) * 0.1
+        r = None
+        wmix = master.double().unsqueeze(0).expand(B, *wshape)
+        bias = torch.randn((cout,), generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = wmix.clone().requires_grad_(True)
+
+    def ref_conv(xb, w, b):
+        if tr:
+            return F.conv_transpose3d(xb, w, b, stride=s, padding=p, output_padding=s - 1)
+        return F.conv3d(xb, w, b, stride=s, padding=p)
+
+    yr = torch.cat([ref_conv(xr[i:i + 1], wr[i], (bias[i] if per_sample else bias).double()) for i in range(B)], 0)
+    gy = torch.randn(yr.shape, generator=g).double()
+    yr.backward(gy)
+    dev = "cuda"
+    xi = to_int(x).to(dev, torch.float32).requires_grad_(True)
+    # the library must pick the fp32 MFMA kernels for these shapes (forward, data gradient and weight gradient)
+    Bo, Do, Ho, Wo = ops.conv_out_grid(xi.shape, k, s, tr)
+    a_f, a_d = ops.pick_algo(tuple(xi.shape), torch.float32, cout, k, s, tr, per_sample, xi.device, 0)
+    assert a_f == 3 and (a_d == 3 or (cin % 32 != 0 and s == 2)), (a_f, a_d)   # (a 16-channel strided dgrad output stays on the direct kernel)
+    mg = master.to(dev).requires_grad_(True)
+    rg = r.to(dev) if per_sample else None
+    wk_f, wk_d = ops.PrepWeights.apply(mg, rg, tr, torch.float32, torch.float32)
+    y = ops.Conv.apply(xi, wk_f, wk_d, bias.to(dev), k, s, tr, per_sample, 0, None)
+    assert rel(to_ext(y), yr) < 2e-5
+    wk_f.retain_grad()
+    y.backward(to_int(gy).to(dev, torch.float32))
+    assert rel(to_ext(xi.grad), xr.grad) < 2e-5
+    gw = wr.grad
+    if tr:
+        gw = gw.permute(0, 2, 1, 3, 4, 5)
+    gw = gw.reshape(B, cout, cin, k ** 3).permute(0, 3, 1, 2)
+    if not per_sample:
+        gw = gw.sum(0, keepdim=True)
+    assert rel(wk_f.grad, gw) < 2e-5
+    yt = L.Tensor(None, L.F32, B, Do, Ho, Wo, cout, cout, 0)
+    xt = L.Tensor(None, L.F32, B, *xi.shape[1:4], cin, cin, 0)
+    assert L.lib.coma_conv_wgrad_algo(ops._desc(k, s, 1 if tr else 0, per_sample, 0), xt, yt) == 3
+
+
 @pytest.mark.parametrize("B,NC,E,N", [(1, 5, 8, 32), (2, 6, 8, 512), (4, 5, 8, 1), (8, 6, 8, 64)])
 def test_routing_matches_torch(B, NC, E, N):
     """CondConv routing: sigmoid(Linear(cov)) and the per-sample bias mix, forward and backward,
