@@ -30,6 +30,7 @@ from .layers import (Config, Convolution, MonaiConvBlock, CondConvolution, CondC
                      conv_then_bn)
 from .ops import Out
 from .roi_tables import ROI_INDICES, ROI_NAMES, ROI_INDEX_TO_NAME
+from .metrics import RoiCorrMetric, calc_roi_metrics          # noqa: F401  (:36-96, :1361-1397 of the reference module)
 
 
 def to_internal(x: torch.Tensor) -> torch.Tensor:
@@ -348,3 +349,8 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         if self.decoder_ds:
             return out_ext, projected, final_proj, []
         return out_ext, projected, final_proj
+
+
+# the host loops of the reference module (train_dp :696, contrastive_test :1129, print_metrics :1109): same names here,
+# so `attn_unet_data_parallel.train_dp(...)` of validation.py:158 resolves after the import swap
+from .train_loop import train_dp, contrastive_test, print_metrics, record_results, extract_id   # noqa: E402,F401

@@ -99,3 +99,53 @@ def ssim3d(y_pred, y, data_range=1.0, kernel_type="gaussian", win_size=11, kerne
     cs = (2 * sxy + c2) / (sx + sy + c2)
     full = ((2 * mu_x * mu_y + c1) / (mu_x ** 2 + mu_y ** 2 + c1)) * cs
     return full.reshape(full.shape[0], -1).mean(1)
+
+
+def contrastive_test_accumulate(batches, roi_indices, ssim_fn=None):
+    """Literal CPU restatement of the accumulation of contrastive_test (attn_unet_data_parallel.py:1147-1347) over
+    `batches` = [(pred, tau_volume, roi, abeta, tau_path)], i.e. everything after the model call of :1209, quirks
+    included: `mape / mape_smp_count` with a counter that is never incremented (:1302), whole-batch terms added once per
+    sample of a class (:1270-1296), `abeta[0]` deciding the class of every sample's ROI means (:1246).
+    Returns (general, pos, neg) 10-tuples like the reference (SSIM through `ssim_fn`, default the restatement above)."""
+    ssim_fn = ssim_fn or ssim3d
+    n_roi = len(roi_indices)
+
+    def fresh():
+        return dict(n=0, mae=0, mape=0, rse=0, rrmse=0, cnt=0, maes=torch.zeros(n_roi), mapes=torch.zeros(n_roi),
+                    rses=torch.zeros(n_roi), wrr=torch.zeros(n_roi), nonnan=torch.zeros(n_roi), ssim=[],
+                    corr=RoiCorrMetric(roi_indices))
+    A, P, N = fresh(), fresh(), fresh()
+    for pred, tau_volume, roi, abeta, tau_path in batches:
+        diff = pred - tau_volume
+        g = batch_global_metrics(pred, tau_volume)
+        raw_mape = torch.abs(diff / tau_volume)
+        A["mae"] += g["mae"]; A["mape"] += g["mape_sum"]; A["rse"] += g["rse"]; A["rrmse"] += g["rrmse"]
+        A["ssim"].append(ssim_fn(pred, tau_volume))
+        for b in range(pred.size(0)):
+            if abeta[b] == 1:
+                P["ssim"].append(ssim_fn(pred[b][None], tau_volume[b][None]))
+            elif abeta[b] == 0:
+                N["ssim"].append(ssim_fn(pred[b][None], tau_volume[b][None]))
+        A["corr"].acc_roi_corr(pred, tau_volume, roi)
+        for b in range(pred.size(0)):
+            (P if abeta[0] == 1 else N)["corr"].acc_roi_corr(pred[b], tau_volume[b], roi[b])
+        z = torch.zeros(n_roi)
+        t = calc_roi_metrics(roi_indices, None, z, z, z, z, z, tau_volume, roi, pred, diff, raw_mape)
+        for k, v in zip(("maes", "mapes", "rses", "wrr", "nonnan"), t):
+            A[k] = A[k] + v
+        A["n"] += pred.size(0)
+        for b in range(pred.size(0)):
+            C = P if abeta[b] == 1 else (N if abeta[b] == 0 else None)
+            if C is None:
+                continue
+            C["mae"] += g["mae"]; C["mape"] += g["mape_sum"]; C["cnt"] += g["mape_count"]
+            C["rse"] += g["rse"]; C["rrmse"] += g["rrmse"]
+            for k, v in zip(("maes", "mapes", "rses", "wrr", "nonnan"), t):
+                C[k] = C[k] + v
+            C["n"] += 1
+
+    def fin(C):
+        ssim = float(torch.cat(C["ssim"]).mean()) if C["ssim"] else float("nan")
+        return (C["mae"] / C["n"], C["mape"] / C["cnt"], C["rse"] / C["n"], C["rrmse"] / C["n"], ssim, C["maes"] / C["n"],
+                (C["mapes"] * 100) / C["nonnan"], C["rses"] / C["n"], C["wrr"] / C["n"], C["corr"].calc_roi_corr())
+    return fin(A), fin(P), fin(N)

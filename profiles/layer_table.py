@@ -10,11 +10,12 @@ from coma_unet_amd.criterions import build_reference_criterion
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=128)
 ap.add_argument("--batch", type=int, default=2)
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 S = (a.size,) * 3
-model = cu.build_model(volume_shape=S, compute_dtype=torch.bfloat16, static_prompts=True).to(dev)
+model = cu.build_model(volume_shape=S, compute_dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32, static_prompts=True).to(dev)
 model.set_save_attn(None)
 model.train(True)
 crit = build_reference_criterion(dev)

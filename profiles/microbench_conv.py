@@ -25,11 +25,12 @@ def main():
     ap.add_argument("--what", default="fwd", choices=["fwd", "dgrad", "wgrad", "all"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--per-sample", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     a = ap.parse_args()
     dev = "cuda"
     torch.manual_seed(0)
     S = a.size
-    x = torch.randn((a.batch, S, S, S, a.cin), device=dev).bfloat16().requires_grad_(True)
+    x = torch.randn((a.batch, S, S, S, a.cin), device=dev).to(torch.bfloat16 if a.dtype == 'bf16' else torch.float32).requires_grad_(True)
     wshape = (a.cin, a.cout, a.k, a.k, a.k) if a.transposed else (a.cout, a.cin, a.k, a.k, a.k)
     if a.per_sample:
         master = (torch.randn((8, *wshape), device=dev) * 0.05).requires_grad_(True)
