@@ -6,10 +6,15 @@
 
 One step = forward + GenerativeContrastiveLoss + backward + gradient all-reduce (N > 1) + fused
 AdamW on one batch of seeded synthetic volumes already resident in HBM.
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant convolution kernel family measured
-live with HIP events around each of its launches inside the timed region; `cpu_baseline` is the CPU
-oracle (this repo's restatement of the reference path -- the reference itself cannot be imported)
-timed on the host cores on a bounded sample, rank 0, N = 1 only.
+Rank 0 prints ONE JSON line.
+ * `roofline`: the dominant convolution KERNEL (by name, as rocprofv3 prints it -- the library reports the variant each
+   dispatch launched, coma_last_kernel): achieved = summed algorithmic FLOPs (or bytes) of its launches / summed launch
+   durations, measured live with HIP events on the launching stream; `step` carries the step-level figure (U-Net FLOPs x
+   volumes / step time / peak).  `traffic` = HBM bytes per launch from the committed PMC pass of the same kernel
+   (profiles/r02_pmc_traffic.json; FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes), null if absent.
+ * `cpu_baseline`: the CPU oracle (this repo's restatement of the reference path -- the reference itself cannot be
+   imported) timed on the host cores: 1 warm-up + median of 3 fwd+bwd steps, rank 0, N = 1 only.
+ * `parity`: rel-L2 and voxel MAE of THIS run's model (same weights, same inputs) against that oracle's forward.
 """
 import argparse
 import json
@@ -23,13 +28,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-FP32_VALU_PEAK_TFLOPS = 157.3
+FP32_VALU_PEAK_TFLOPS = 157.3     # = the fp32 MFMA peak (v_mfma_f32_32x32x2_f32 runs at the vector rate)
 HBM_PEAK_GBPS = 8000.0
 UNET_TFLOP_PER_VOLUME_128 = 2.340  # BASELINE.md section 2 (U-Net fwd+bwd, 128^3)
 
 
-def cpu_baseline(size, threads, batch=2):
-    """One fwd+bwd step of the CPU oracle at `size`^3 on the same per-GPU batch (bounded sample of the workload)."""
+def cpu_baseline(size, threads, batch=2, gpu_model_factory=None):
+    """CPU oracle fwd+bwd at `size`^3 on the same per-GPU batch: 1 warm-up + median of 3 steps.
+    With `gpu_model_factory` the GPU model is loaded with the oracle's weights and run on the same inputs: -> parity."""
     from oracle.coma_oracle import build_reference_model
     from oracle.criterions_oracle import build_reference_criterion, train_step_loss
     from coma_unet_amd.synthetic import make_batch
@@ -41,13 +47,46 @@ def cpu_baseline(size, threads, batch=2):
     m.train(True)
     b = make_batch(batch, S, seed=0)
     crit = build_reference_criterion()
-    t0 = time.perf_counter()
-    out = m(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])
-    train_step_loss(out, b["tau"], b["roi"], b["covars"], crit)[0].backward()
-    dt = time.perf_counter() - t0
-    return {"value": batch / dt, "unit": "volumes/s", "cores": threads, "kind": "port",
-            "sample": f"CPU oracle (torch {torch.__version__}, fp32, single U-Net pass), 1 fwd+bwd step, "
-                      f"batch {batch} at {size}^3, {dt:.1f} s"}
+    sd = {k: v.clone() for k, v in m.state_dict().items()}     # before any step moves the BatchNorm running buffers
+    times, out0 = [], None
+    for it in range(4):
+        m.zero_grad(set_to_none=True)
+        t0 = time.perf_counter()
+        out = m(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])
+        train_step_loss(out, b["tau"], b["roi"], b["covars"], crit)[0].backward()
+        times.append(time.perf_counter() - t0)
+        if out0 is None:
+            out0 = out[0].detach().clone()
+    dt = sorted(times[1:])[1]
+    base = {"value": batch / dt, "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"CPU oracle (torch {torch.__version__}, fp32, single U-Net pass), fwd+bwd of batch {batch} at {size}^3: "
+                      f"1 warm-up + median of 3 steps = {dt:.1f} s ({', '.join(f'{t:.1f}' for t in times)})"}
+    parity = None
+    if gpu_model_factory is not None:
+        gm = gpu_model_factory()
+        gm.load_state_dict(sd, strict=True)
+        gm.train(True)
+        with torch.no_grad():
+            go = gm(b["mri"].cuda(), b["covars"].cuda(), roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"].cuda())
+        g = go[0].float().cpu()
+        parity = {"rel_l2": float((g - out0).norm() / out0.norm()), "voxel_mae": float((g - out0).abs().mean()),
+                  "against": f"CPU oracle fp32 forward, same weights and inputs, batch {batch} at {size}^3 (oracle parity unpinned: DESIGN.md section 3)"}
+        del gm
+    return base, parity
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json,
+    written by profiles/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        tab = json.load(open(path))
+    except Exception:
+        return None
+    ent = tab.get(kernel_name)
+    return ent if ent is None else float(ent["hbm_bytes_per_launch"])
 
 
 def main():
@@ -159,28 +198,38 @@ def main():
         vols = args.batch * world * args.steps
         value = vols / elapsed
         summ = ops.KernelTimer.summary()
+        byk = ops.KernelTimer.by_kernel()
         roof = None
         kernels = {}
+        unet_tf = UNET_TFLOP_PER_VOLUME_128 * (args.size / 128.0) ** 3
+        peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else FP32_VALU_PEAK_TFLOPS
+        step_ach = value * unet_tf
+        step_roof = {"unet_tflop_per_volume": round(unet_tf, 4), "achieved_tflops": round(step_ach, 2), "peak": peak_tf,
+                     "frac": round(step_ach / peak_tf, 4)}
         if summ:
             for (kind, algo), (n, ms, fl, by) in sorted(summ.items()):
                 kernels[f"{kind}/{algo}"] = {"launches": n, "ms_total": round(ms, 3),
                                              "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
                                              "alg_GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-            (kind, algo), (n, ms, fl, by) = max(summ.items(), key=lambda kv: kv[1][1])
-            common = {"kernel": f"{kind}/{algo}", "traffic": None, "launches": n, "avg_launch_ms": round(ms / n, 4),
-                      "step_tflops_all_convs": round(sum(v[2] for v in summ.values()) / timer_steps / 1e12, 3),
-                      "measured": timer_note}
-            if algo == "mfma-thin":     # zero-padded thin layers: bytes, not FLOPs, are the algorithmic work
+            top = sorted(byk.items(), key=lambda kv: -kv[1][1])
+            kname, (n, ms, fl, by) = top[0]
+            thin = fl / max(by, 1.0) < 150.0      # below the MFMA/HBM ridge (~300 FLOP/B) by 2x: a bandwidth kernel
+            common = {"kernel": kname, "launches_per_step": n / timer_steps, "avg_launch_us": round(ms / n * 1e3, 2),
+                      "alg_flops_per_launch": round(fl / n), "alg_bytes_per_launch": round(by / n),
+                      "traffic": pmc_traffic(kname), "step": step_roof, "measured": timer_note,
+                      "top_kernels": [{"kernel": k, "launches_per_step": v[0] / timer_steps, "ms_per_step": round(v[1] / timer_steps, 3),
+                                       "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1), "alg_GBps": round(v[3] / (v[1] * 1e-3) / 1e9)}
+                                      for k, v in top[:8]]}
+            if thin:
                 ach = by / (ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBPS, 4), **common}
             else:
-                peak = MFMA_BF16_PEAK_TFLOPS if algo.startswith("mfma") else FP32_VALU_PEAK_TFLOPS
                 ach = fl / (ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), **common}
+                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                        "frac": round(ach / peak_tf, 4), **common}
         line = {
-            "metric": "volumes/sec (train fwd+bwd) at 128^3 bf16", "value": round(value, 4), "unit": "volumes/s",
+            "metric": f"volumes/sec (train fwd+bwd) at 128^3 {args.dtype}", "value": round(value, 4), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -191,7 +240,7 @@ def main():
                                  if use_graph else "eager (hook-driven all-reduce overlap)",
                        "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 1)},
             "loss": round(loss, 4), "note": graph_note,
-            "unet_tflops_per_s": round(value * UNET_TFLOP_PER_VOLUME_128 * (args.size / 128.0) ** 3, 2),
+            "unet_tflops_per_s": round(step_ach, 2),
             "roofline": roof, "conv_kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -200,7 +249,12 @@ def main():
             except Exception:
                 threads = os.cpu_count() or 1
             threads = min(threads, 16)   # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
-            line["cpu_baseline"] = cpu_baseline(args.size, threads, args.batch)
+            del model, opt, crit
+            if use_graph:
+                del step_fn, run_step
+            torch.cuda.empty_cache()
+            factory = lambda: (lambda mm: (mm.set_save_attn(None), mm)[1])(cu.build_model(volume_shape=S, compute_dtype=dt).to(dev))
+            line["cpu_baseline"], line["parity"] = cpu_baseline(args.size, threads, args.batch, factory)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

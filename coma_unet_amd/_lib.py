@@ -36,6 +36,7 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_si
 SIGNATURES = {
     "coma_abi_version": (_i32, []),
     "coma_last_error": (C.c_char_p, []),
+    "coma_last_kernel": (C.c_char_p, []),
     "coma_weight_prep": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
     "coma_weight_prep_pair": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "coma_weight_prep_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),

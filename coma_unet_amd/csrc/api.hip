@@ -11,6 +11,16 @@ void coma_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local char g_ktag[160] = "";
+
+void coma_set_kernel_tag(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_ktag, sizeof(g_ktag), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* coma_last_kernel(void) { return g_ktag; }
 extern "C" int coma_abi_version(void) { return COMA_ABI_VERSION; }
 extern "C" const char* coma_last_error(void) { return g_err; }
 

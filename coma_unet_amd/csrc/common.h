@@ -9,6 +9,9 @@
 typedef __bf16 bf16_t;
 
 void coma_set_error(const char* fmt, ...);
+// name of the convolution kernel variant a dispatch is about to launch (as rocprofv3 prints it): the host reads it back
+// through coma_last_kernel() to label its per-launch HIP-event timings (bench.py's roofline leg)
+void coma_set_kernel_tag(const char* fmt, ...);
 
 #define COMA_CHECK(cond, ...)                         \
   do {                                                \

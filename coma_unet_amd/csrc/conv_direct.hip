@@ -73,6 +73,7 @@ template <typename T, int NT>
 static int launch_fwd_vec(const ConvP& p, int B, int vec, hipStream_t s) {
   const int64_t M = (int64_t)p.Do * p.Ho * p.Wo;
   dim3 grid((unsigned)((M + 255) / 256), (unsigned)(p.N / NT), (unsigned)B);
+  coma_set_kernel_tag("conv_direct_fwd_k<%s, %d, %d>", sizeof(T) == 4 ? "float" : "__bf16", NT, vec >= 4 ? 4 : 1);
   if (vec >= 4) hipLaunchKernelGGL((conv_direct_fwd_k<T, NT, 4>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((conv_direct_fwd_k<T, NT, 1>), grid, dim3(256), 0, s, p);
   COMA_LAUNCH_CHECK();
@@ -237,6 +238,7 @@ int conv_direct_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_
   p.mch = (int)mch;
   p.ntn = (dy->C + TILE - 1) / TILE; p.ntc = (x->C + TILE - 1) / TILE;
   dim3 grid((unsigned)((M + mch - 1) / mch), (unsigned)(taps * p.ntn * p.ntc), (unsigned)x->B);
+  coma_set_kernel_tag("conv_direct_wgrad_k<%s, %d>", x->dtype == COMA_F32 ? "float" : "__bf16", TS);
 #define WG_LAUNCH(T, TSV) hipLaunchKernelGGL((conv_direct_wgrad_k<T, TSV>), grid, dim3(256), 0, s, p)
   if (x->dtype == COMA_F32) {
     if (TS == 4) WG_LAUNCH(float, 4); else if (TS == 2) WG_LAUNCH(float, 2); else WG_LAUNCH(float, 1);

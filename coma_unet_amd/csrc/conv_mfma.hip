@@ -1029,6 +1029,7 @@ static int launch_gather(const GatherP& p0, int mode, int B, hipStream_t s, void
     if (hipMemsetAsync(ws, 0, sizeof(float) * (size_t)B * Vout * p.N, s) != hipSuccess) { coma_set_error("conv split-K memset failed"); return 2; }
   } else p.ksplit = 1;
   dim3 grid(gx, gy * p.ksplit, (unsigned)B);
+  coma_set_kernel_tag("conv_mfma_gather_k<%d, %d, %s>", BN, mode, LCK == 4 ? "float" : "__bf16");
   if (mode == 0) hipLaunchKernelGGL((conv_mfma_gather_k<BN, 0, T>), grid, dim3(256), lds, s, p);
   else hipLaunchKernelGGL((conv_mfma_gather_k<BN, 1, T>), grid, dim3(256), lds, s, p);
   COMA_LAUNCH_CHECK();
@@ -1052,6 +1053,7 @@ static int launch_halo(const HaloP& p0, int B, hipStream_t s) {
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)conv_mfma_halo_k<CK, LX, VEC, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
   dim3 grid((unsigned)(p.ntx * p.nty * ((p.ntz + 7) / 8) * 8), (unsigned)((p.N + 31) / 32), (unsigned)B);
+  coma_set_kernel_tag("conv_mfma_halo_k<%d, %d, %d, %s>", CK, LX, VEC, sizeof(T) == 4 ? "float" : "__bf16");
   hipLaunchKernelGGL((conv_mfma_halo_k<CK, LX, VEC, T>), grid, dim3(256), lds, s, p);
   COMA_LAUNCH_CHECK();
   return 0;
@@ -1116,6 +1118,8 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
       }
       attr = true;
     }
+    coma_set_kernel_tag(F32 ? "conv_mfma_halo2_k<2, 16, 1, 1, float>" : thin ? "conv_mfma_halo2_k<1, 16, 0, 2, __bf16>"
+                        : resident ? "conv_mfma_halo2_k<1, 32, 1, 1, __bf16>" : "conv_mfma_halo2_k<2, 32, 1, 1, __bf16>");
     if constexpr (F32) {
       hipLaunchKernelGGL((conv_mfma_halo2_k<2, 16, 1, 1, float>), grid, dim3(256), lds, s, q);
     } else {
@@ -1179,6 +1183,7 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
       *stats_chunks = stats_inst ? (int)nb : (int)nb * x->B;
     }
     dim3 grid((unsigned)nb, (unsigned)x->B);
+    coma_set_kernel_tag("conv_mfma_pw_k<%d, %d>", ks > 4 ? 4 : ks, nt);
 #define PWL(K_, N_) hipLaunchKernelGGL((conv_mfma_pw_k<K_, N_>), grid, dim3(256), 0, s, q)
     if (nt == 1) { if (ks == 1) PWL(1, 1); else if (ks == 2) PWL(2, 1); else if (ks == 3) PWL(3, 1); else PWL(4, 1); }
     else { if (ks == 1) PWL(1, 2); else if (ks == 2) PWL(2, 2); else if (ks == 3) PWL(3, 2); else PWL(4, 2); }
@@ -1244,6 +1249,8 @@ struct WgradP2 {
   int vec_n, vec_c;    // 16-byte loads legal on dy / x
   unsigned m_hx, m_hxy; // magic multipliers: n / hx == umulhi(n, m_hx), n / (hx*hy) == umulhi(n, m_hxy)
   int plain;           // every dwk element is produced by exactly one block: plain stores, no memset, no atomics
+  int cp, pg;          // fp32 kernel: gathered channels per tap in an MFMA tile (power of two <= 32), gathered LDS row pitch (bytes)
+  int nrep; long rep_stride;   // fp32 kernel, small outputs: blocks merge into one of nrep replicas (summed afterwards)
 };
 
 template <int TN, int TC, int FORM, int VEC>
@@ -1421,22 +1428,30 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
 
 // =====================================================================================
 // conv_f32_wgrad_k -- the weight gradient in fp32 mode on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
-// accumulation).  Same block structure as conv_mfma_wgrad_k (one 32 x 32 slab of dwk per block, dense tile + gathered
-// halo staged once in LDS as [voxel][32 channels] fp32 rows, the 27 taps dealt to the 4 waves, accumulators stationary
-// over the block's tiles), but the MFMA reduces over TWO voxels per instruction and takes one fp32 per lane and operand:
-// lane (channel = lane & 31, voxel = lane >> 5) reads its value with a plain ds_read_b32 -- 32 consecutive floats per
-// half-wave, conflict-free, no transposed reads.  An fp32 MFMA occupies the SIMD for 64 cycles, so the two LDS reads and
-// the address arithmetic per MFMA sit in its shadow; the next voxel pair's fragments are read one step ahead.
+// accumulation).  Same block structure as conv_mfma_wgrad_k (one slab of dwk per block, dense tile + gathered halo staged
+// once in LDS as [voxel][channel] fp32 rows, accumulators stationary over the block's tiles), but the MFMA reduces over
+// TWO voxels per instruction and takes one fp32 per lane and operand: lane (index = lane & 31, voxel = lane >> 5) reads
+// its value with a plain ds_read_b32 -- no transposed reads.  An fp32 MFMA occupies the SIMD for 64 cycles, so the LDS
+// reads and the address arithmetic of a voxel pair sit in its shadow; the next pair's fragments are read one step ahead.
+//
+// The 32 indices of the GATHERED operand are (tap, channel) pairs: with >= 32 gathered channels an MFMA tile is one tap
+// x 32 channels (27 tiles); with fewer channels (the 1..16-channel layers of the full-resolution tail) CP = next power
+// of two >= C channels of 32 / CP taps share a tile (14, 7, 4, 2 or 1 tiles instead of 27) -- the tap offset is just a
+// per-lane constant in the gathered read's address.  The tiles are dealt to min(4, tiles) wave groups; with fewer than
+// four tiles the remaining waves split the voxel pairs.  NT = tiles per wave is a template parameter: every wave runs
+// NT unconditional MFMAs per pair (a wave with fewer real tiles recomputes one into an accumulator that is never
+// stored), so the pipeline has no wave-dependent control flow and hipcc keeps its counted lgkmcnt waits.
 // =====================================================================================
-template <int FORM>
+template <int FORM, int NT>
 __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
-  constexpr int PR = 128;                            // LDS row pitch (bytes): 32 fp32 channels
-  constexpr int MAXT = 7;                            // taps per wave
-  constexpr int MAXP = 34;                           // 16-byte staging pieces per thread (host guarantees the fit)
+  constexpr int PD = 128;                            // dense LDS row pitch (bytes): 32 fp32 channels, zero padded
+  constexpr int MAXP = NT == 7 ? 24 : 34;            // 16-byte staging pieces per thread (host guarantees the fit; 7 tiles
+                                                     // per wave = 112 accumulator registers leave room for 24)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int TM = 1 << (p.lx + p.ly + p.lz);
+  const int PG = p.pg;                               // gathered LDS row pitch (bytes): max(CP, 4) channels
   char* Dt = smem;
-  char* Gt = smem + TM * PR;
+  char* Gt = smem + TM * PD;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, fh = lane >> 5;
@@ -1449,23 +1464,33 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
   const float* gath = (FORM == 0 ? xp + (long)b * p.sbc + c0 : dyp + (long)b * p.sbn + n0);
   const int ldd = FORM == 0 ? p.ldn : p.ldc, ldg = FORM == 0 ? p.ldc : p.ldn;
   const int chd = (FORM == 0 ? p.N - n0 : p.C - c0), chg = (FORM == 0 ? p.C - c0 : p.N - n0);   // channels left
+  const bool vecd = FORM == 0 ? p.vec_n : p.vec_c, vecg = FORM == 0 ? p.vec_c : p.vec_n;
   const int ntaps = p.k * p.k * p.k;
   const int HV = p.hz * p.hy * p.hx;
   const int tx = 1 << p.lx, ty = 1 << p.ly;
+  const int CP = p.cp, lcp = 31 - __builtin_clz(CP), TPT = 32 >> lcp;       // channels per tap in a tile, taps per tile
+  const int ntiles = (ntaps + TPT - 1) / TPT;
+  const int wt = ntiles >= 4 ? 4 : ntiles, ws = 4 / wt;                       // wave groups over tiles x over voxel pairs
+  const int tg = wid % wt, ps = wid / wt;
 
-  f32x16_t acc[MAXT];
+  f32x16_t acc[NT];
 #pragma unroll
-  for (int t = 0; t < MAXT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-  int tap_w[MAXT], toff_w[MAXT];
+  // this lane's (tap, channel) in each of the wave's tiles -> byte offset of the gathered read; a lane / tile without a
+  // real (tap, channel) reads tap 0 (its column or row of the accumulator is never stored)
+  int goff[NT];
+  const int gch = fr & (CP - 1);
 #pragma unroll
-  for (int t = 0; t < MAXT; ++t) {
-    const int tap = p.k == 1 ? (t == 0 ? 0 : ntaps) : wid + 4 * t;
-    tap_w[t] = tap;
-    const int kx = tap % p.k, ky = (tap / p.k) % p.k, kz = tap / (p.k * p.k);
-    toff_w[t] = __builtin_amdgcn_readfirstlane(((kz * p.hy + ky) * p.hx + kx) * PR);
+  for (int t = 0; t < NT; ++t) {
+    const int i = tg + wt * t;
+    const int tap = i * TPT + (fr >> lcp);
+    const bool ok = i < ntiles && tap < ntaps && gch < chg;
+    const int tp = ok ? tap : 0;
+    const int kx = tp % p.k, ky = (tp / p.k) % p.k, kz = tp / (p.k * p.k);
+    goff[t] = ((kz * p.hy + ky) * p.hx + kx) * PG + (ok ? gch : 0) * 4;
   }
 
   const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * p.tiles_per_block;
@@ -1474,7 +1499,20 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
 
   // ---- staging: 16-byte pieces (4 channels), the next tile's loads in flight while this tile computes ----
   uint4 sv[MAXP];
-  const int ndp = TM * 8, ngp = HV * 8;
+  const int gpr = PG >> 4;                            // pieces per gathered row
+  const int ndp = TM * 8, ngp = HV * gpr;
+  auto ld4 = [&](const float* src, int nvalid, bool vec) -> uint4 {     // 4 channels of which nvalid (>= 1) exist
+    if (vec) {
+      uint4 v = *reinterpret_cast<const uint4*>(src);
+      if (nvalid < 4) { v.w = 0; if (nvalid < 3) v.z = 0; if (nvalid < 2) v.y = 0; }
+      return v;
+    }
+    uint4 v = make_uint4(__float_as_uint(src[0]), 0, 0, 0);
+    if (nvalid > 1) v.y = __float_as_uint(src[1]);
+    if (nvalid > 2) v.z = __float_as_uint(src[2]);
+    if (nvalid > 3) v.w = __float_as_uint(src[3]);
+    return v;
+  };
   auto load_tile = [&](int x0, int y0, int z0) {
     const int bz = z0 * p.stride - p.pad, by = y0 * p.stride - p.pad, bx = x0 * p.stride - p.pad;
 #pragma unroll
@@ -1486,15 +1524,15 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
         const int vx = row & (tx - 1), vy = (row >> p.lx) & (ty - 1), vz = row >> (p.lx + p.ly);
         const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
         if (gz < p.Mz && gy < p.My && gx < p.Mx && ch * 4 < chd)
-          sv[u] = *reinterpret_cast<const uint4*>(dense + (unsigned)(((gz * p.My + gy) * p.Mx + gx) * ldd + ch * 4));
+          sv[u] = ld4(dense + (unsigned)(((gz * p.My + gy) * p.Mx + gx) * ldd + ch * 4), chd - ch * 4, vecd);
       } else if (piece < ndp + ngp) {
         const int pg = piece - ndp;
-        const int row = pg >> 3, ch = pg & 7;
+        const int row = pg / gpr, ch = pg - row * gpr;
         const int q1 = (int)__umulhi((unsigned)row, p.m_hx), hzi = (int)__umulhi((unsigned)row, p.m_hxy);
         const int hxi = row - q1 * p.hx, hyi = q1 - hzi * p.hy;
         const int gz = bz + hzi, gy = by + hyi, gx = bx + hxi;
         if ((unsigned)gz < (unsigned)p.Gz && (unsigned)gy < (unsigned)p.Gy && (unsigned)gx < (unsigned)p.Gx && ch * 4 < chg)
-          sv[u] = *reinterpret_cast<const uint4*>(gath + (unsigned)(((gz * p.Gy + gy) * p.Gx + gx) * ldg + ch * 4));
+          sv[u] = ld4(gath + (unsigned)(((gz * p.Gy + gy) * p.Gx + gx) * ldg + ch * 4), chg - ch * 4, vecg);
       }
     }
   };
@@ -1506,28 +1544,25 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
     }
   };
 
-  // one voxel pair (2 q, 2 q + 1: x neighbours of one row) -> the lane's dense value and its taps' gathered values
-  const int lane_d = fh * PR + fr * 4, lane_g = fh * p.stride * PR + fr * 4;
-  auto rd = [&](int q, float& d, float (&g)[MAXT]) {
+  // one voxel pair (2 q, 2 q + 1: x neighbours of one row) -> the lane's dense value and its tiles' gathered values
+  const int lane_d = fh * PD + fr * 4, lane_g = fh * p.stride * PG;
+  auto rd = [&](int q, float& d, float (&g)[NT]) {
     const int v = 2 * q;
     const int x = v & (tx - 1), y = (v >> p.lx) & (ty - 1), z = v >> (p.lx + p.ly);
-    d = *reinterpret_cast<const float*>(Dt + v * PR + lane_d);
-    const char* gp = Gt + ((z * p.stride * p.hy + y * p.stride) * p.hx + x * p.stride) * PR + lane_g;
+    d = *reinterpret_cast<const float*>(Dt + v * PD + lane_d);
+    const char* gp = Gt + ((z * p.stride * p.hy + y * p.stride) * p.hx + x * p.stride) * PG + lane_g;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-      if (tap_w[t] < ntaps) g[t] = *reinterpret_cast<const float*>(gp + toff_w[t]);
+    for (int t = 0; t < NT; ++t) g[t] = *reinterpret_cast<const float*>(gp + goff[t]);
   };
-  auto mm = [&](float d, const float (&g)[MAXT]) {
+  auto mm = [&](float d, const float (&g)[NT]) {
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-      if (tap_w[t] < ntaps) {
-        if (FORM == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(d, g[t], acc[t], 0, 0, 0);
-        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t], d, acc[t], 0, 0, 0);
-      }
+    for (int t = 0; t < NT; ++t) {
+      if (FORM == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(d, g[t], acc[t], 0, 0, 0);
+      else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t], d, acc[t], 0, 0, 0);
+    }
   };
 
-  const int npairs = TM >> 1;
-  const int qs = p.k == 1 ? 4 : 1, q0 = p.k == 1 ? wid : 0;   // 1x1x1: the 4 waves share the single tap by voxel pair
+  const int npairs = TM >> 1;                               // (a multiple of 8)
   int tile = tile_begin, tix = 0, tiy = 0, tiz = 0;
   while (tile < tile_end && !tile_coords(tile, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++tile;
   if (tile < tile_end) load_tile(tix << p.lx, tiy << p.ly, tiz << p.lz);
@@ -1538,16 +1573,14 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
     store_tile();
     __syncthreads();
     if (nt < tile_end) load_tile(ntix << p.lx, ntiy << p.ly, ntiz << p.lz);
-    float dA, dB, gA[MAXT], gB[MAXT];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) { gA[t] = 0.f; gB[t] = 0.f; }
-    rd(q0, dA, gA);
-    for (int q = q0; q < npairs; q += 2 * qs) {          // (npairs is a multiple of 8)
-      rd(q + qs, dB, gB);
+    float dA, dB, gA[NT], gB[NT];
+    rd(ps, dA, gA);
+    for (int q = ps; q < npairs; q += 2 * ws) {
+      rd(q + ws, dB, gB);
       __builtin_amdgcn_sched_barrier(0);
       mm(dA, gA);
       __builtin_amdgcn_sched_barrier(0);
-      if (q + 2 * qs < npairs) rd(q + 2 * qs, dA, gA);
+      rd(q + 2 * ws < npairs ? q + 2 * ws : ps, dA, gA);        // (the last step re-reads pair `ps`: harmless, keeps the loop uniform)
       __builtin_amdgcn_sched_barrier(0);
       mm(dB, gB);
       __builtin_amdgcn_sched_barrier(0);
@@ -1555,19 +1588,23 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
     tile = nt; tix = ntix; tiy = ntiy; tiz = ntiz;
   }
   // ---- merge into dwk[b][tap][n][c] ----
-  float* wout = p.dwk + (long)b * p.wsb;
+  float* wout = p.dwk + (long)b * p.wsb + (long)(blockIdx.x % (unsigned)p.nrep) * p.rep_stride;
 #pragma unroll
-  for (int t = 0; t < MAXT; ++t) {
-    const int tap = tap_w[t];
-    if (tap < ntaps) {
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        const int c = c0 + fr;
-        if (n < p.N && c < p.C) {
-          if (p.plain) wout[((long)tap * p.N + n) * p.C + c] = acc[t][e];
-          else atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, acc[t][e]);
-        }
+    for (int e = 0; e < 16; ++e) {
+      const int r = (e & 3) + 8 * (e >> 2) + 4 * fh;        // accumulator row of this element; the lane's column is fr
+      int tap, n, c;
+      if (FORM == 0) {       // rows = dense n, columns = gathered (tap, c)
+        const int i = tg + wt * t, tp = i * TPT + (fr >> lcp);
+        tap = (i < ntiles && tp < ntaps && gch < chg) ? tp : -1; n = n0 + r; c = c0 + gch;
+      } else {               // rows = gathered (tap, n), columns = dense c: the row's (tap, n) is lane-independent
+        const int i = tg + wt * t, tp = i * TPT + (r >> lcp), nn = r & (CP - 1);
+        tap = (i < ntiles && tp < ntaps && nn < chg) ? tp : -1; n = n0 + nn; c = c0 + fr;
+      }
+      if (tap >= 0 && n < p.N && c < p.C) {
+        if (p.plain) wout[((long)tap * p.N + n) * p.C + c] = acc[t][e];
+        else atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, acc[t][e]);
       }
     }
   }
@@ -1841,6 +1878,7 @@ static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const
   }
   const bool vec = p.vec_n && p.vec_c && p.N % 8 == 0 && p.C % 8 == 0;
   const dim3 grid((unsigned)chunks, (unsigned)pairs, (unsigned)x->B);
+  coma_set_kernel_tag("conv_mfma_wgrad2_k<%d, 2, %d, %d>", (int)vec, d->ksize, d->ksize == 1 ? 1 : p.C <= 8 ? 4 : p.C <= 16 ? 2 : 1);
 #define WG2(K_, PK_) do { if (vec) hipLaunchKernelGGL((conv_mfma_wgrad2_k<1, 2, K_, PK_>), grid, dim3(256), lds, s, p); \
                           else hipLaunchKernelGGL((conv_mfma_wgrad2_k<0, 2, K_, PK_>), grid, dim3(256), lds, s, p); } while (0)
   if (d->ksize == 1) WG2(1, 1);
@@ -1865,10 +1903,6 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   pl.ok = false;
   const bool f32 = x->dtype == COMA_F32 && dy->dtype == COMA_F32;
   if (!f32 && (x->dtype != COMA_BF16 || dy->dtype != COMA_BF16)) return pl;
-  if (f32) {   // fp32 kernel: 16-byte pieces of 4 channels, vector staging only; >= 16 channels a side (below that: conv_direct)
-    if (x->C % 4 || dy->C % 4 || x->C < 16 || dy->C < 16 || x->ld % 4 || dy->ld % 4 || x->sb % 4 || dy->sb % 4) return pl;
-    if ((x->data && !aligned16(x->data)) || (dy->data && !aligned16(dy->data))) return pl;
-  }
   if (d->ksize != 3 && d->ksize != 1) return pl;
   if ((long)t_vox(x) * x->ld >= (1L << 31) || (long)t_vox(dy) * dy->ld >= (1L << 31)) return pl;
   if (d->form == 1 && d->stride != 2) return pl;
@@ -1880,15 +1914,21 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   const coma_tensor* ga = d->form == 0 ? x : dy;     // gathered
   p.Mz = dn->D; p.My = dn->H; p.Mx = dn->W; p.Gz = ga->D; p.Gy = ga->H; p.Gx = ga->W;
   p.k = d->ksize; p.stride = d->stride; p.pad = d->pad;
-  p.vec_n = dy->ld % 8 == 0 && dy->sb % 8 == 0 && (!dy->data || aligned16(dy->data));
-  p.vec_c = x->ld % 8 == 0 && x->sb % 8 == 0 && (!x->data || aligned16(x->data));
+  const int vq = f32 ? 4 : 8;                        // elements per 16-byte piece
+  p.vec_n = dy->ld % vq == 0 && dy->sb % vq == 0 && (!dy->data || aligned16(dy->data));
+  p.vec_c = x->ld % vq == 0 && x->sb % vq == 0 && (!x->data || aligned16(x->data));
   pl.tn = (dy->C > 32 && !(x->C > 32 && x->C > dy->C)) ? 2 : 1;
   pl.tc = (pl.tn == 1 && x->C > 32) ? 2 : 1;
   if (f32) pl.tn = pl.tc = 1;
-  const int esz = f32 ? 4 : 2, ppc = f32 ? 4 : 8, maxp = f32 ? 34 : 20;   // bytes per element, channels per piece, pieces per thread
+  const int gch = d->form == 0 ? x->C : dy->C;
+  // bytes per element, channels per piece, 16-byte staging pieces per thread (fp32: 24 with 7 MFMA tiles per wave, else 34)
+  const int esz = f32 ? 4 : 2, ppc = f32 ? 4 : 8, maxp = f32 ? ((gch >= 32 && d->ksize == 3) ? 24 : 34) : 20;
+  // fp32 kernel: the gathered operand's 32 MFMA indices are (tap, channel) pairs -- cp channels (a power of two) per tap
+  p.cp = 32; p.pg = 128;
+  if (f32 && gch < 32) { p.cp = 1; while (p.cp < gch) p.cp <<= 1; p.pg = (p.cp < 4 ? 4 : p.cp) * 4; }
   // tile: up to 256 dense voxels at stride 1, 64 at stride 2 (the halo grows 8x); shrink until the LDS image
   // and the per-thread register staging budget (20 x 16-byte pieces) fit
-  const int cdb = 32 * (d->form == 0 ? pl.tn : pl.tc), cgb = 32 * (d->form == 0 ? pl.tc : pl.tn);
+  const int cdb = 32 * (d->form == 0 ? pl.tn : pl.tc), cgb = f32 ? p.pg / 4 : 32 * (d->form == 0 ? pl.tc : pl.tn);
   bool fits = false;
   for (int budget = d->stride == 1 ? 8 : 6; budget >= 4 && !fits; --budget) {
     int lx = ilog2_ceil(p.Mx); if (lx > 5) lx = 5;
@@ -1926,6 +1966,8 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   p.tiles_per_block = (p.tiles_total + chunks - 1) / chunks;
   chunks = (p.tiles_total + p.tiles_per_block - 1) / p.tiles_per_block;
   p.plain = chunks == 1 && (d->per_sample_w || x->B == 1);
+  if (f32 && p.cp < 8 && d->ksize == 3) p.plain = 0;     // fewer than 4 MFMA tiles: several waves of a block sum the same outputs
+  if (f32 && d->ksize == 1) p.plain = 0;                  // 1x1x1: the four waves split the voxel pairs of the single tile
   pl.grid = dim3((unsigned)chunks, (unsigned)pairs, (unsigned)x->B);
   const long taps = (long)d->ksize * d->ksize * d->ksize;
   p.wsb = d->per_sample_w ? taps * p.N * p.C : 0;
@@ -1938,7 +1980,7 @@ bool conv_mfma_wgrad_supported(const coma_conv_desc* d, const coma_tensor* x, co
 }
 size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   const long wsz = wgrad_out_elems(d, x, dy);
-  return wgrad2_ok(d, x, dy) && wsz <= WGRAD_REP_MAX_ELEMS ? sizeof(float) * wsz * WGRAD_NREP : 0;
+  return (wgrad2_ok(d, x, dy) || x->dtype == COMA_F32) && wsz <= WGRAD_REP_MAX_ELEMS ? sizeof(float) * wsz * WGRAD_NREP : 0;
 }
 
 int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws, size_t ws_bytes,
@@ -1950,15 +1992,36 @@ int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_te
   const long wsz = (long)d->ksize * d->ksize * d->ksize * dy->C * x->C * (d->per_sample_w ? x->B : 1);
   if (!pl.p.plain && hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
   if (x->dtype == COMA_F32) {
+    // small outputs (the 1..16-channel layers): hundreds of blocks merging into a few cache lines serialise in the
+    // atomic unit -- they merge into WGRAD_NREP replicas in the workspace, summed by one small kernel (as wgrad2 does)
+    const bool replicas = !pl.p.plain && wsz <= WGRAD_REP_MAX_ELEMS && ws && ws_bytes >= sizeof(float) * wsz * WGRAD_NREP;
+    pl.p.nrep = replicas ? WGRAD_NREP : 1;
+    pl.p.rep_stride = replicas ? wsz : 0;
+    if (replicas) {
+      pl.p.dwk = (float*)ws;
+      if (hipMemsetAsync(ws, 0, sizeof(float) * wsz * WGRAD_NREP, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+    }
+    const int taps = d->ksize * d->ksize * d->ksize, tpt = 32 / pl.p.cp, ntiles = (taps + tpt - 1) / tpt;
+    const int nt = (ntiles + 3) / 4;                  // tiles per wave: 27 -> 7, 14 -> 4, 7 -> 2, <= 4 -> 1
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)conv_f32_wgrad_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_f32_wgrad_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define F32ATTR(F, N_) (void)hipFuncSetAttribute((const void*)conv_f32_wgrad_k<F, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+      F32ATTR(0, 1); F32ATTR(0, 2); F32ATTR(0, 4); F32ATTR(0, 7); F32ATTR(1, 1); F32ATTR(1, 2); F32ATTR(1, 4); F32ATTR(1, 7);
+#undef F32ATTR
       attr = true;
     }
-    if (d->form == 0) hipLaunchKernelGGL((conv_f32_wgrad_k<0>), pl.grid, dim3(256), pl.lds, s, pl.p);
-    else hipLaunchKernelGGL((conv_f32_wgrad_k<1>), pl.grid, dim3(256), pl.lds, s, pl.p);
+    coma_set_kernel_tag("conv_f32_wgrad_k<%d, %d>", d->form, nt == 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 7);
+#define F32WL(F) do { if (nt == 1) hipLaunchKernelGGL((conv_f32_wgrad_k<F, 1>), pl.grid, dim3(256), pl.lds, s, pl.p); \
+                      else if (nt == 2) hipLaunchKernelGGL((conv_f32_wgrad_k<F, 2>), pl.grid, dim3(256), pl.lds, s, pl.p); \
+                      else if (nt <= 4) hipLaunchKernelGGL((conv_f32_wgrad_k<F, 4>), pl.grid, dim3(256), pl.lds, s, pl.p); \
+                      else hipLaunchKernelGGL((conv_f32_wgrad_k<F, 7>), pl.grid, dim3(256), pl.lds, s, pl.p); } while (0)
+    if (d->form == 0) F32WL(0); else F32WL(1);
+#undef F32WL
     COMA_LAUNCH_CHECK();
+    if (replicas) {
+      hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
+      COMA_LAUNCH_CHECK();
+    }
     return 0;
   }
   const bool vecall = pl.p.vec_n && pl.p.vec_c && dy->C % 8 == 0 && x->C % 8 == 0;
@@ -1974,6 +2037,7 @@ int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_te
       hipLaunchKernelGGL((conv_mfma_wgrad_k<TNV, TCV, F, 0>), pl.grid, dim3(256), pl.lds, s, pl.p);              \
     }                                                                                                            \
   } while (0)
+  coma_set_kernel_tag("conv_mfma_wgrad_k<%d, %d, %d, %d>", pl.tn, pl.tc, d->form, (int)vecall);
   if (d->form == 0) {
     if (pl.tn == 2) WL(2, 1, 0); else if (pl.tc == 2) WL(1, 2, 0); else WL(1, 1, 0);
   } else {

@@ -184,6 +184,7 @@ int conv_point1_fwd(const coma_conv_desc* d, const coma_tensor* x, const float* 
     p.wsb = d->per_sample_w ? x->C : 0; p.bsb = d->per_sample_w ? 1 : 0;
     p.cp = pieces(x);
     dim3 grid(p1_grid(p.V, p.cp), (unsigned)x->B);
+    coma_set_kernel_tag("p1_dot_k<%s>", x->dtype == COMA_F32 ? "float" : "__bf16");
     if (x->dtype == COMA_F32) hipLaunchKernelGGL(p1_dot_k<float>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(p1_dot_k<bf16_t>, grid, dim3(256), 0, s, p);
   } else {
@@ -192,6 +193,7 @@ int conv_point1_fwd(const coma_conv_desc* d, const coma_tensor* x, const float* 
     p.wsb = d->per_sample_w ? y->C : 0; p.bsb = d->per_sample_w ? y->C : 0;
     p.cp = pieces(y);
     dim3 grid(p1_grid(p.V, p.cp), (unsigned)x->B);
+    coma_set_kernel_tag("p1_scale_k<%s>", x->dtype == COMA_F32 ? "float" : "__bf16");
     if (x->dtype == COMA_F32) hipLaunchKernelGGL(p1_scale_k<float>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(p1_scale_k<bf16_t>, grid, dim3(256), 0, s, p);
   }
@@ -214,6 +216,7 @@ int conv_point1_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_
   unsigned nb = p1_grid(p.V, p.cp);
   if (nb > 512) nb = 512;
   dim3 grid(nb, (unsigned)x->B);
+  coma_set_kernel_tag("p1_wsum_k<%s>", x->dtype == COMA_F32 ? "float" : "__bf16");
   if (x->dtype == COMA_F32) hipLaunchKernelGGL(p1_wsum_k<float>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(p1_wsum_k<bf16_t>, grid, dim3(256), 0, s, p);
   COMA_LAUNCH_CHECK();

@@ -26,7 +26,7 @@ class KernelTimer:
     """Optional HIP-event bracket around every convolution launch (bench.py's live roofline leg).
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
     enabled = False
-    records = []   # (kind, algo, flops, ev_start, ev_end)
+    records = []   # (kind, algo, flops, ev_start, ev_end, layer tag, kernel name)
 
     @classmethod
     def run(cls, kind, algo, flops, fn, tag=None):
@@ -36,15 +36,28 @@ class KernelTimer:
         e0.record()
         r = fn()
         e1.record()
-        cls.records.append((kind, algo, flops, e0, e1, tag))
+        # the kernel variant the library just launched, spelled as rocprofv3 prints it (coma_last_kernel)
+        cls.records.append((kind, algo, flops, e0, e1, tag, lib.coma_last_kernel().decode()))
         return r
+
+    @classmethod
+    def by_kernel(cls):
+        """{kernel name: (launches, total_ms, total_flops, total_bytes)} -- call after torch.cuda.synchronize().  A bracket
+        also covers the small helper launches of a dispatch (split-K merge, replica sum, memset): they are part of the
+        layer's cost and are attributed to its main kernel."""
+        out = {}
+        for kind, algo, fb, e0, e1, _tag, kname in cls.records:
+            fl, by = fb if isinstance(fb, tuple) else (fb, 0.0)
+            n, ms, f0, b0 = out.get(kname, (0, 0.0, 0.0, 0.0))
+            out[kname] = (n + 1, ms + e0.elapsed_time(e1), f0 + fl, b0 + by)
+        return out
 
     @classmethod
     def summary(cls):
         """{(kind, algo): (launches, total_ms, total_flops, total_bytes)} -- call after torch.cuda.synchronize().
         `flops` entries are (flops, algorithmic_bytes) pairs."""
         out = {}
-        for kind, algo, fb, e0, e1, _tag in cls.records:
+        for kind, algo, fb, e0, e1, _tag, _k in cls.records:
             fl, by = fb if isinstance(fb, tuple) else (fb, 0.0)
             n, ms, f0, b0 = out.get((kind, algo), (0, 0.0, 0.0, 0.0))
             out[(kind, algo)] = (n + 1, ms + e0.elapsed_time(e1), f0 + fl, b0 + by)
@@ -54,7 +67,7 @@ class KernelTimer:
     def by_layer(cls):
         """{(kind, tag): (launches, total_ms, total_flops)} for the per-layer table (profiles/layer_table.py)."""
         out = {}
-        for kind, algo, fb, e0, e1, tag in cls.records:
+        for kind, algo, fb, e0, e1, tag, _k in cls.records:
             fl = fb[0] if isinstance(fb, tuple) else fb
             n, ms, f0 = out.get((kind, tag), (0, 0.0, 0.0))
             out[(kind, tag)] = (n + 1, ms + e0.elapsed_time(e1), f0 + fl)

@@ -78,6 +78,10 @@ typedef struct coma_conv_desc {
 
 int         coma_abi_version(void);
 const char* coma_last_error(void);
+/* name of the convolution kernel variant the calling thread's most recent coma_conv_* call launched, spelled as
+ * rocprofv3 prints it (e.g. "conv_mfma_halo2_k<2, 32, 1, 1>"): lets a host-side timer attribute its per-launch HIP-event
+ * durations to the kernel names of a rocprofv3 --kernel-trace of the same command. */
+const char* coma_last_kernel(void);
 
 /* ---- CondConv expert mixing + weight re-layout  (replaces CondConv.CondConvolution's
  *      per-sample kernel synthesis, call sites attn_unet_data_parallel.py:126,285-306) ----

@@ -45,6 +45,21 @@ CONV_CASES = [
 @pytest.mark.parametrize("per_sample", [False, True])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_bwd(case, per_sample, dtype):
+    _conv_case(case, per_sample, dtype, 1)
+
+
+@pytest.mark.parametrize("per_sample", [False, True])
+@pytest.mark.parametrize("case", CONV_CASES + [(1, 32, 3, 1, False, 33), (3, 16, 3, 1, False, 34), (16, 1, 3, 1, False, 35),
+                                               (2, 8, 3, 1, False, 33), (8, 8, 3, 1, False, 40), (8, 1, 3, 1, False, 32),
+                                               (16, 16, 3, 1, False, 32), (12, 20, 3, 1, False, 9), (32, 16, 1, 1, False, 12)])
+def test_conv_fwd_bwd_fp32_auto(case, per_sample):
+    """fp32 tensors with algo 0 (what the model runs in fp32 mode): whichever kernel family the library picks per shape --
+    direct, streaming 1-channel, fp32 MFMA, and the tap-packed fp32 MFMA weight gradient of the few-channel layers --
+    must meet the fp32 bound against the fp64 reference."""
+    _conv_case(case, per_sample, torch.float32, 0)
+
+
+def _conv_case(case, per_sample, dtype, algo):
     ops, L = _ops()
     cin, cout, k, s, tr, S = case
     B, E = 2, 3
@@ -89,7 +104,7 @@ def test_conv_fwd_bwd(case, per_sample, dtype):
     rg = r.float().to(dev).requires_grad_(True) if per_sample else None
     bg = bias.float().to(dev).requires_grad_(True)
     wk_f, wk_d = ops.PrepWeights.apply(mg, rg, tr, torch.float32, torch.float32)
-    y = ops.Conv.apply(xi, wk_f, wk_d, bg, k, s, tr, per_sample, 1, None)
+    y = ops.Conv.apply(xi, wk_f, wk_d, bg, k, s, tr, per_sample, algo, None)
     assert rel(to_ext(y), yr) < TOL[dtype]
     y.backward(to_int(gy).to(dev, dtype))
     tol = TOL[dtype]
