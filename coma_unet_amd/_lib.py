@@ -73,6 +73,13 @@ SIGNATURES = {
     "coma_ssim_partial": (_i32, [_TP, _TP, _vp, _i32, _f32, _f32, _vp, _sz, _vp, _vp]),
     "coma_resample_nearest": (_i32, [_vp, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _vp, _i32, _i32, _i32,
                               C.c_double, C.c_double, C.c_double, _f32, _i32, _vp, _vp]),
+    "coma_comm_unique_id": (_i32, [_vp]),
+    "coma_comm_init": (_i32, [_vp, _i32, _i32, C.POINTER(C.c_void_p)]),
+    "coma_comm_destroy": (_i32, [_vp]),
+    "coma_allreduce_sum_f32": (_i32, [_vp, _vp, _i64, _vp]),
+    "coma_reduce_scatter_sum_f32": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "coma_allgather_f32": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "coma_broadcast_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "coma_adamw": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
 }
 

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcoma_unet.so")
-SOURCES = ["api.hip", "conv_direct.hip", "conv_point1.hip", "conv_mfma.hip", "norm.hip", "elementwise.hip", "weights.hip", "metrics.hip"]
+SOURCES = ["api.hip", "conv_direct.hip", "conv_point1.hip", "conv_mfma.hip", "norm.hip", "elementwise.hip", "weights.hip", "metrics.hip", "comm.hip"]
 
 
 def _stale(obj, deps):
@@ -34,7 +34,7 @@ def build(force=False, verbose=True):
     if failed:
         raise RuntimeError(f"hipcc failed for {failed}")
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

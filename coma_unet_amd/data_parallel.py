@@ -185,3 +185,170 @@ class GradReducer:
         rest = [p for p in params if id(p) not in opt._flat_ids and p.grad is not None]
         for p in rest:
             dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+
+
+class TorchComm:
+    """The communicator interface of rccl_comm.RcclComm on torch.distributed collectives (any backend; gloo on CPU for
+    the multi-process tests).  `side` is None: the collectives run synchronously on the caller's stream."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.side = None
+
+    def all_reduce_(self, t, stream=None):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def reduce_scatter(self, send, recv, stream=None):
+        tmp = send.clone()                      # (gloo has no reduce_scatter: all-reduce a copy, keep this rank's slice)
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+        n = recv.numel()
+        recv.copy_(tmp[self.rank * n:(self.rank + 1) * n])
+
+    def all_gather(self, send, recv, stream=None):
+        parts = [torch.empty_like(send) for _ in range(self.world)]
+        dist.all_gather(parts, send.contiguous(), group=self.group)
+        recv.copy_(torch.cat(parts))
+
+    def broadcast_(self, t, root=0, stream=None):
+        dist.broadcast(t, src=root, group=self.group)
+
+
+class StreamedGradExchange:
+    """Bucketed gradient exchange of FusedAdamW's flat gradient buffer on the communicator's side stream, driven by the
+    backward kernels themselves: with write-through gradients (ops.GradSink) every parameter gradient is written by a HIP
+    kernel straight into its slot of the flat buffer; the sink tells this object which slots have been written, and as
+    soon as the last slot of a bucket is on the compute stream the bucket's collective is enqueued on the side stream
+    behind an event -- no autograd hooks, so it works unchanged while the step is being CAPTURED into a hipGraph: the
+    replayed graph then contains forward, backward, the overlapped exchange, the join and the optimizer step.
+
+    sharded=False: SUM all-reduce of each bucket, then the caller's optimizer.step() on the whole buffer.
+    sharded=True:  SUM reduce-scatter of each bucket (rank r keeps sub-slice r of every bucket), `finish()` runs the
+                   fused AdamW on this rank's sub-slices only (1/world of the 4 reads + 3 writes per parameter) and
+                   all-gathers the updated parameters in place -- same bytes on the wire as the all-reduce.
+    Buckets whose parameters are not all written through (autograd-accumulated gradients) go out at finish()."""
+
+    def __init__(self, optimizer, comm, bucket_bytes=64 << 20, sharded=False):
+        self.opt, self.comm, self.sharded = optimizer, comm, sharded
+        self.world = comm.world
+        self.bucket_elems = max(self.world, bucket_bytes // 4)
+        self._buckets = None          # [start, end, params_total]
+        self._left = None
+        self._pending = []
+        self._launched = None
+        self._forked = False
+
+    # -- layout ---------------------------------------------------------------------------------------------------
+    def _build(self):
+        opt = self.opt
+        assert opt.built, "the flat gradient layout exists after the first optimizer step"
+        n = opt.flat_g.numel()
+        assert n % self.world == 0 or not self.sharded, "FusedAdamW(pad_to=world) keeps the flat buffer divisible by the world size"
+        bounds, start = [], 0
+        for p in opt._flat_params:
+            off, k = opt._offsets[id(p)]
+            end = off + k
+            if end - start >= self.bucket_elems:
+                if self.sharded:
+                    end -= (end - start) % self.world          # shardable buckets; the remainder opens the next bucket
+                if end > start:
+                    bounds.append((start, end))
+                    start = end
+        if start < n:
+            bounds.append((start, n))
+        self._buckets = bounds
+        self._p2b = {}
+        self._total = [0] * len(bounds)
+        for p in opt._flat_params:
+            off, k = opt._offsets[id(p)]
+            bs = [i for i, (s0, e0) in enumerate(bounds) if off < e0 and off + k > s0]
+            self._p2b[id(p)] = bs
+            for i in bs:
+                self._total[i] += 1
+
+    # -- per step -------------------------------------------------------------------------------------------------
+    def begin(self):
+        """Call before backward (after optimizer.zero_grad())."""
+        from . import ops
+        if self._buckets is None and self.opt.built:
+            self._build()
+        ops.GradSink.listener = self if self._buckets is not None else None
+        if self._buckets is not None:
+            self._left = list(self._total)
+            self._launched = [False] * len(self._buckets)
+        self._pending = []
+        self._forked = False
+
+    def mark(self, p):
+        for i in self._p2b.get(id(p), ()):
+            self._left[i] -= 1
+            if self._left[i] == 0:
+                self._pending.append(i)
+
+    def flush_pending(self):
+        if self._pending:
+            todo, self._pending = self._pending, []
+            for i in todo:
+                self._launch(i)
+
+    def _launch(self, i):
+        if self._launched[i]:
+            return
+        self._launched[i] = True
+        s0, e0 = self._buckets[i]
+        g = self.opt.flat_g[s0:e0]
+        side = self.comm.side
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())       # the bucket's last gradient kernel is on the compute stream
+            self._forked = True
+        if self.sharded:
+            k = (e0 - s0) // self.world
+            self.comm.reduce_scatter(g, g[self.comm.rank * k:(self.comm.rank + 1) * k], stream=side)
+        else:
+            self.comm.all_reduce_(g, stream=side)
+
+    def finish(self, step=True):
+        """Call after backward: sends what is left, joins the side stream, and (sharded) steps + re-gathers."""
+        from . import ops
+        ops.GradSink.listener = None
+        opt = self.opt
+        if self._buckets is None:          # first step: no flat layout yet -> whole-tensor all-reduces, as GradReducer
+            for p in opt.param_groups[0]["params"]:
+                if p.grad is not None:
+                    self.comm.all_reduce_(p.grad.contiguous().view(-1) if p.grad.is_contiguous() else p.grad)
+            return False
+        self._pending = []
+        for i in range(len(self._buckets)):
+            self._launch(i)
+        rest = [p for p in opt.param_groups[0]["params"] if id(p) not in opt._flat_ids and p.grad is not None]
+        side = self.comm.side
+        for p in rest:
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+            self.comm.all_reduce_(p.grad.view(-1), stream=side)
+        if not self.sharded:
+            if side is not None and self._forked:
+                torch.cuda.current_stream().wait_stream(side)
+            return False
+        # sharded: AdamW on this rank's sub-slice of every bucket (on the side stream, right behind its reduce-scatter),
+        # then the all-gather of the updated parameters
+        ctx = torch.cuda.stream(side) if side is not None else _null()
+        with ctx:
+            if step:
+                opt.step_shards([(s0 + self.comm.rank * ((e0 - s0) // self.world), (e0 - s0) // self.world) for s0, e0 in self._buckets])
+            for s0, e0 in self._buckets:
+                k = (e0 - s0) // self.world
+                pb = opt.flat_p[s0:e0]
+                self.comm.all_gather(pb[self.comm.rank * k:(self.comm.rank + 1) * k], pb, stream=side)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        return True      # the optimizer step has been taken
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -114,6 +114,7 @@ class GradSink:
     same parameter inside one step falls back to the ordinary returned gradient (autograd adds it to the slot).
     Post-accumulate-grad hooks do not fire for sunk gradients, so hook-driven overlap keeps this off."""
     written = set()
+    listener = None      # data_parallel.StreamedGradExchange: told which gradient slots have been written
 
     @classmethod
     def begin_step(cls):
@@ -121,9 +122,15 @@ class GradSink:
 
     @classmethod
     def slot(cls, p):
+        # a new request proves that the kernels of every earlier request have been enqueued (python runs the backward
+        # nodes one after another on one stream): buckets those completed may go on the wire now
+        if cls.listener is not None:
+            cls.listener.flush_pending()
         if p is None or not getattr(p, "_coma_sink", False) or p.grad is None or id(p) in cls.written:
             return None
         cls.written.add(id(p))
+        if cls.listener is not None:
+            cls.listener.mark(p)
         return p.grad
 
 

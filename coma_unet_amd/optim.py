@@ -16,7 +16,8 @@ from . import ops
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, dynamic=(), write_through=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, dynamic=(), write_through=False,
+                 pad_to=1):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         assert len(self.param_groups) == 1, "one parameter group (the reference uses one)"
@@ -28,6 +29,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # (ops.GradSink) -- no per-parameter AccumulateGrad launch.  Off when a GradReducer drives its
         # all-reduce from post-accumulate-grad hooks (those do not fire for sunk gradients).
         self.write_through = write_through
+        self.pad_to = max(1, int(pad_to))   # flat buffers padded to a multiple of this (the world size, for sharded steps)
 
     # -- layout -------------------------------------------------------------------------
     def _build(self):
@@ -35,8 +37,9 @@ class FusedAdamW(torch.optim.Optimizer):
         assert ps, "no parameter has a gradient"
         dev = ps[0].device
         n = sum(p.numel() for p in ps)
-        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_g = torch.empty(n, dtype=torch.float32, device=dev)
+        n = (n + self.pad_to - 1) // self.pad_to * self.pad_to
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
@@ -85,14 +88,24 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
+        self.step_shards(None)
+
+    @torch.no_grad()
+    def step_shards(self, shards):
+        """One AdamW step.  shards=None: the whole flat buffer (one launch).  shards=[(offset, length)]: only those slices
+        of it -- the data-parallel step with a reduce-scattered gradient updates this rank's slices and all-gathers the
+        parameters afterwards (data_parallel.StreamedGradExchange); the moments of the other slices are never touched here
+        (they live, up to date, on the ranks that own them)."""
         g = self.param_groups[0]
         lr, (b1, b2), eps, wd = float(g["lr"]), g["betas"], g["eps"], g["weight_decay"]
         if not self.built:
             self._build()
         self._flat_step += 1
         self._step_dev += 1            # device-side copy: a captured step keeps counting under graph replay
-        ops.adamw_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, lr, b1, b2, eps, wd, self._flat_step,
-                   self._step_dev)
+        for off, k in ([(0, self.flat_p.numel())] if shards is None else shards):
+            if k > 0:
+                ops.adamw_(self.flat_p[off:off + k], self.flat_g[off:off + k], self.flat_m[off:off + k], self.flat_v[off:off + k],
+                           lr, b1, b2, eps, wd, self._flat_step, self._step_dev)
         for p in g["params"]:
             if id(p) in self._flat_ids or p.grad is None:
                 continue

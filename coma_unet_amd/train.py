@@ -8,14 +8,15 @@ from __future__ import annotations
 import torch
 
 from .optim import FusedAdamW
-from .data_parallel import GradReducer
+from .data_parallel import GradReducer, StreamedGradExchange
 
 
-def make_optimizer(model, lr=1e-3, write_through=True):
+def make_optimizer(model, lr=1e-3, write_through=True, pad_to=1):
     """torch.optim.AdamW(model.parameters(), lr) of :736, fused.  ``write_through``: parameter gradients are
-    written by the backward kernels straight into the optimizer's flat gradient buffer (see ops.GradSink)."""
+    written by the backward kernels straight into the optimizer's flat gradient buffer (see ops.GradSink).
+    ``pad_to``: the world size when the step is sharded over ranks (StreamedGradExchange(sharded=True))."""
     dyn = [model.pos_dynamic_prompt, model.neg_dynamic_prompt] if not getattr(model, "static_prompts", False) else []
-    return FusedAdamW(model.parameters(), lr=lr, dynamic=dyn, write_through=write_through)
+    return FusedAdamW(model.parameters(), lr=lr, dynamic=dyn, write_through=write_through, pad_to=pad_to)
 
 
 def forward_loss(model, criterion, batch, global_rnc=False):
@@ -43,13 +44,18 @@ def train_step(model, criterion, optimizer, batch, reducer: GradReducer = None, 
         # sequences diverge (hang, or pos paired with neg)
         assert getattr(model, "static_prompts", False), "data parallel steps need a model built with static_prompts=True"
     optimizer.zero_grad()                                                   # :806
-    if reducer is not None:
+    streamed = isinstance(reducer, StreamedGradExchange)
+    if streamed:
+        reducer.begin()
+    elif reducer is not None:
         reducer.reset()
     losses, outs = forward_loss(model, criterion, batch, global_rnc)
     losses[0].backward()                                                    # :884
+    stepped = False
     if reducer is not None:
-        reducer.finish()
-    optimizer.step()                                                        # :885
+        stepped = bool(reducer.finish())       # (a sharded exchange also takes the optimizer step, on its shard)
+    if not stepped:
+        optimizer.step()                                                    # :885
     return losses, outs
 
 
@@ -63,12 +69,15 @@ class GraphedTrainStep:
     passed as a (B,36,2) tensor, fixed shapes.  New data is copied into the static input buffers.
     """
 
-    def __init__(self, model, criterion, optimizer, batch, warmup=3, reducer: GradReducer = None):
+    def __init__(self, model, criterion, optimizer, batch, warmup=3, reducer=None):
         assert getattr(model, "static_prompts", False), "graph capture needs static_prompts=True"
         self.model, self.criterion, self.optimizer, self.reducer = model, criterion, optimizer, reducer
         self.batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         assert torch.is_tensor(self.batch["roi_pred_dicts"]), "pass ROI priors as a (B, 36, 2) device tensor"
-        if reducer is not None:
+        # a StreamedGradExchange enqueues its collectives through the C ABI on a forked side stream: the WHOLE step
+        # (forward, backward, overlapped exchange, join, optimizer) is captured as one graph, as on one GPU
+        self.in_graph = isinstance(reducer, StreamedGradExchange)
+        if reducer is not None and not self.in_graph:
             reducer.overlap = False          # hooks do not fire under replay
             reducer.remove_hooks()
             optimizer.set_write_through(True)
@@ -95,13 +104,13 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread may query events while this thread captures
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            if reducer is None:
-                self.losses, self.outputs = train_step(model, criterion, optimizer, self.batch)
+            if reducer is None or self.in_graph:
+                self.losses, self.outputs = train_step(model, criterion, optimizer, self.batch, reducer)
             else:
                 optimizer.zero_grad()
                 self.losses, self.outputs = forward_loss(model, criterion, self.batch)
                 self.losses[0].backward()
-        if reducer is None:
+        if reducer is None or self.in_graph:
             # capture executes nothing: undo the host-side step count train_step's optimizer.step() just added
             optimizer._flat_step -= 1
 
@@ -113,10 +122,11 @@ class GraphedTrainStep:
     def __call__(self, batch=None):
         if batch is not None:
             self.load(batch)
-        if self.reducer is None and self._hyper() != self._captured_hyper:
+        whole = self.reducer is None or self.in_graph
+        if whole and self._hyper() != self._captured_hyper:
             self._capture()
         self.graph.replay()
-        if self.reducer is None:
+        if whole:
             self.optimizer._flat_step += 1
         else:
             self.reducer.reduce_flat()

@@ -232,6 +232,25 @@ int coma_resample_nearest(const float* src, int32_t Dz, int32_t Hy, int32_t Wx, 
                           double nsp_y, double nsp_x, float default_value, int32_t nan_to_num,
                           const float* zero_where, void* stream);
 
+/* ---- data-parallel gradient exchange over RCCL / xGMI (SURVEY.md section 8(b) last row, 8(e)): replaces the
+ *      torch.nn.DataParallel the reference imports but never applies (attn_unet_data_parallel.py:32,1554).
+ * One communicator per process (= per GPU).  Rank 0 creates the 128-byte id, the host distributes it by any means
+ * (the Python host uses its torch.distributed group), every rank calls coma_comm_init on ITS device.  Collectives are
+ * enqueued on the stream passed in -- a side HIP stream, so that a bucket's exchange overlaps the rest of backward -- and
+ * never synchronise the host; they may be captured into a hipGraph.  All buffers are fp32 device pointers, reduction
+ * is SUM (the reference sums the per-sample losses, criterions.py:560).  RCCL is bound at run time: an instance already
+ * loaded in the process (PyTorch's) is shared.                                                                     */
+#define COMA_COMM_ID_BYTES 128
+int coma_comm_unique_id(void* id_out /* host, COMA_COMM_ID_BYTES */);
+int coma_comm_init(const void* id /* host */, int32_t rank, int32_t nranks, void** comm_out);
+int coma_comm_destroy(void* comm);
+int coma_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);                       /* in place */
+/* recv[n_per_rank] = this rank's slice of the sum of every rank's send[nranks * n_per_rank]; recv may alias that slice */
+int coma_reduce_scatter_sum_f32(void* comm, const float* send, float* recv, int64_t n_per_rank, void* stream);
+/* recv[nranks * n_per_rank] = concatenation of every rank's send[n_per_rank]; send may alias its own slice of recv */
+int coma_allgather_f32(void* comm, const float* send, float* recv, int64_t n_per_rank, void* stream);
+int coma_broadcast_f32(void* comm, float* buf, int64_t n, int32_t root, void* stream);            /* in place */
+
 #ifdef __cplusplus
 }
 #endif
