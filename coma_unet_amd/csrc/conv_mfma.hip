@@ -10,6 +10,7 @@
 // Replaces the cuDNN dispatches behind nn.Conv3d / nn.ConvTranspose3d forward and data-gradient
 // in the reference model (attn_unet_data_parallel.py; MONAI Convolution / CondConv call sites).
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one MFMA A/B fragment
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 accumulator fragment
@@ -1445,8 +1446,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
 template <int FORM, int NT>
 __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
   constexpr int PD = 128;                            // dense LDS row pitch (bytes): 32 fp32 channels, zero padded
-  constexpr int MAXP = NT == 7 ? 24 : 34;            // 16-byte staging pieces per thread (host guarantees the fit; 7 tiles
-                                                     // per wave = 112 accumulator registers leave room for 24)
+  constexpr int MAXP = 24;                           // 16-byte staging pieces per thread (host guarantees the fit)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int TM = 1 << (p.lx + p.ly + p.lz);
   const int PG = p.pg;                               // gathered LDS row pitch (bytes): max(CP, 4) channels
@@ -1501,46 +1501,56 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
   uint4 sv[MAXP];
   const int gpr = PG >> 4;                            // pieces per gathered row
   const int ndp = TM * 8, ngp = HV * gpr;
-  auto ld4 = [&](const float* src, int nvalid, bool vec) -> uint4 {     // 4 channels of which nvalid (>= 1) exist
-    if (vec) {
-      uint4 v = *reinterpret_cast<const uint4*>(src);
-      if (nvalid < 4) { v.w = 0; if (nvalid < 3) v.z = 0; if (nvalid < 2) v.y = 0; }
-      return v;
-    }
-    uint4 v = make_uint4(__float_as_uint(src[0]), 0, 0, 0);
-    if (nvalid > 1) v.y = __float_as_uint(src[1]);
-    if (nvalid > 2) v.z = __float_as_uint(src[2]);
-    if (nvalid > 3) v.w = __float_as_uint(src[3]);
-    return v;
-  };
-  auto load_tile = [&](int x0, int y0, int z0) {
+  // A staged piece = 4 channels of which 1..4 exist.  Every load of the tile is issued UNCONDITIONALLY from a clamped
+  // address and nothing touches its result before store_tile: a conditional load (or a mask applied right away) makes
+  // hipcc copy the value after an s_waitcnt vmcnt(0) -- 24 serialised L2 round trips per tile, half the kernel's time.
+  // Validity (inside the volume / inside the tensor's channels) travels as one bit per piece and is applied at the LDS
+  // store.  The vector / element-wise choice is made ONCE around the whole unrolled loop for the same reason.
+  const int lgpr = 31 - __builtin_clz(gpr);           // (gpr = 1, 2, 4 or 8)
+  unsigned long long okbits = 0;
+#define F32WG_LOAD_LOOP(LD4)                                                                                            \
+  _Pragma("unroll") for (int u = 0; u < MAXP; ++u) {                                                                    \
+    const int piece = tid + 256 * u;                                                                                    \
+    const bool isd = 256 * u < ndp;      /* block-uniform: ndp = 8 TM is a multiple of 256 -> scalar base pointers */     \
+    const int pg = piece - ndp;                                                                                         \
+    const int row = isd ? piece >> 3 : pg >> lgpr, ch = isd ? piece & 7 : pg & (gpr - 1);                               \
+    const int vx = row & (tx - 1), vy = (row >> p.lx) & (ty - 1), vz = row >> (p.lx + p.ly);                            \
+    const int q1 = (int)__umulhi((unsigned)row, p.m_hx), hzi = (int)__umulhi((unsigned)row, p.m_hxy);                  \
+    const int gz = isd ? z0 + vz : bz + hzi, gy = isd ? y0 + vy : by + (q1 - hzi * p.hy), gx = isd ? x0 + vx : bx + (row - q1 * p.hx); \
+    const int Lz = isd ? p.Mz : p.Gz, Ly = isd ? p.My : p.Gy, Lx = isd ? p.Mx : p.Gx;                                  \
+    const bool ok = piece < ndp + ngp && (unsigned)gz < (unsigned)Lz && (unsigned)gy < (unsigned)Ly &&                  \
+                    (unsigned)gx < (unsigned)Lx && ch * 4 < (isd ? chd : chg);                                          \
+    const unsigned off = ok ? (unsigned)(((gz * Ly + gy) * Lx + gx) * (isd ? ldd : ldg) + ch * 4) : 0u;                 \
+    const float* src = (isd ? dense : gath) + off;                                                                      \
+    const int nvalid = ok ? (isd ? chd : chg) - ch * 4 : 1; (void)nvalid;                                               \
+    okbits |= (unsigned long long)ok << u;                                                                              \
+    sv[u] = LD4;                                                                                                        \
+  }
+  const bool allvec = vecd && vecg;
+  auto load_next = [&](int x0, int y0, int z0) __attribute__((always_inline)) {
     const int bz = z0 * p.stride - p.pad, by = y0 * p.stride - p.pad, bx = x0 * p.stride - p.pad;
-#pragma unroll
-    for (int u = 0; u < MAXP; ++u) {
-      const int piece = tid + 256 * u;
-      sv[u] = make_uint4(0, 0, 0, 0);
-      if (piece < ndp) {
-        const int row = piece >> 3, ch = piece & 7;
-        const int vx = row & (tx - 1), vy = (row >> p.lx) & (ty - 1), vz = row >> (p.lx + p.ly);
-        const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
-        if (gz < p.Mz && gy < p.My && gx < p.Mx && ch * 4 < chd)
-          sv[u] = ld4(dense + (unsigned)(((gz * p.My + gy) * p.Mx + gx) * ldd + ch * 4), chd - ch * 4, vecd);
-      } else if (piece < ndp + ngp) {
-        const int pg = piece - ndp;
-        const int row = pg / gpr, ch = pg - row * gpr;
-        const int q1 = (int)__umulhi((unsigned)row, p.m_hx), hzi = (int)__umulhi((unsigned)row, p.m_hxy);
-        const int hxi = row - q1 * p.hx, hyi = q1 - hzi * p.hy;
-        const int gz = bz + hzi, gy = by + hyi, gx = bx + hxi;
-        if ((unsigned)gz < (unsigned)p.Gz && (unsigned)gy < (unsigned)p.Gy && (unsigned)gx < (unsigned)p.Gx && ch * 4 < chg)
-          sv[u] = ld4(gath + (unsigned)(((gz * p.Gy + gy) * p.Gx + gx) * ldg + ch * 4), chg - ch * 4, vecg);
-      }
-    }
+    okbits = 0;
+    if (allvec) { F32WG_LOAD_LOOP(*reinterpret_cast<const uint4*>(src)) }
+    else { F32WG_LOAD_LOOP(make_uint4(__float_as_uint(src[0]), nvalid > 1 ? __float_as_uint(src[1]) : 0u,
+                                      nvalid > 2 ? __float_as_uint(src[2]) : 0u, nvalid > 3 ? __float_as_uint(src[3]) : 0u)) }
   };
-  auto store_tile = [&]() {
+#undef F32WG_LOAD_LOOP
+  const bool partd = (chd & 3) != 0 && chd < 32, partg = (chg & 3) != 0 && chg < 32;     // a piece with 1..3 valid channels exists
+  auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < MAXP; ++u) {
       const int piece = tid + 256 * u;
-      if (piece < ndp + ngp) reinterpret_cast<uint4*>(smem)[piece] = sv[u];     // dense rows, then halo rows: contiguous
+      if (piece < ndp + ngp) {
+        uint4 v = sv[u];
+        if (!((okbits >> u) & 1)) v = make_uint4(0, 0, 0, 0);
+        if (partd || partg) {       // (block-uniform) channels past the tensor's own: padding or a neighbour's slice -> zero
+          const bool isd = 256 * u < ndp;
+          const int ch = isd ? (piece & 7) : ((piece - ndp) & (gpr - 1));
+          const int nv = (isd ? chd : chg) - ch * 4;
+          if (nv < 4) { v.w = 0; if (nv < 3) v.z = 0; if (nv < 2) v.y = 0; if (nv < 1) v.x = 0; }
+        }
+        reinterpret_cast<uint4*>(smem)[piece] = v;     // dense rows, then halo rows: contiguous
+      }
     }
   };
 
@@ -1565,14 +1575,14 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
   const int npairs = TM >> 1;                               // (a multiple of 8)
   int tile = tile_begin, tix = 0, tiy = 0, tiz = 0;
   while (tile < tile_end && !tile_coords(tile, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++tile;
-  if (tile < tile_end) load_tile(tix << p.lx, tiy << p.ly, tiz << p.lz);
+  if (tile < tile_end) load_next(tix << p.lx, tiy << p.ly, tiz << p.lz);
   while (tile < tile_end) {
     int nt = tile + 1, ntix = 0, ntiy = 0, ntiz = 0;
     while (nt < tile_end && !tile_coords(nt, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nt;
     __syncthreads();   // previous tile's reads are done
     store_tile();
     __syncthreads();
-    if (nt < tile_end) load_tile(ntix << p.lx, ntiy << p.ly, ntiz << p.lz);
+    if (nt < tile_end) load_next(ntix << p.lx, ntiy << p.ly, ntiz << p.lz);
     float dA, dB, gA[NT], gB[NT];
     rd(ps, dA, gA);
     for (int q = ps; q < npairs; q += 2 * ws) {
@@ -1921,8 +1931,8 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   pl.tc = (pl.tn == 1 && x->C > 32) ? 2 : 1;
   if (f32) pl.tn = pl.tc = 1;
   const int gch = d->form == 0 ? x->C : dy->C;
-  // bytes per element, channels per piece, 16-byte staging pieces per thread (fp32: 24 with 7 MFMA tiles per wave, else 34)
-  const int esz = f32 ? 4 : 2, ppc = f32 ? 4 : 8, maxp = f32 ? ((gch >= 32 && d->ksize == 3) ? 24 : 34) : 20;
+  // bytes per element, channels per piece, 16-byte staging pieces per thread
+  const int esz = f32 ? 4 : 2, ppc = f32 ? 4 : 8, maxp = f32 ? 24 : 20;
   // fp32 kernel: the gathered operand's 32 MFMA indices are (tap, channel) pairs -- cp channels (a power of two) per tap
   p.cp = 32; p.pg = 128;
   if (f32 && gch < 32) { p.cp = 1; while (p.cp < gch) p.cp <<= 1; p.pg = (p.cp < 4 ? 4 : p.cp) * 4; }
