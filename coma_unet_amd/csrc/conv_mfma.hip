@@ -1446,7 +1446,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_wgrad_k(WgradP2 p) {
 template <int FORM, int NT>
 __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
   constexpr int PD = 128;                            // dense LDS row pitch (bytes): 32 fp32 channels, zero padded
-  constexpr int MAXP = 24;                           // 16-byte staging pieces per thread (host guarantees the fit)
+  constexpr int MAXP = NT == 7 ? 21 : 24;            // 16-byte staging pieces per thread (host guarantees the fit; with 7 tiles
+                                                     // per wave = 112 accumulator registers 21 is what fits without spilling)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int TM = 1 << (p.lx + p.ly + p.lz);
   const int PG = p.pg;                               // gathered LDS row pitch (bytes): max(CP, 4) channels
@@ -1491,6 +1492,9 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
     const int tp = ok ? tap : 0;
     const int kx = tp % p.k, ky = (tp / p.k) % p.k, kz = tp / (p.k * p.k);
     goff[t] = ((kz * p.hy + ky) * p.hx + kx) * PG + (ok ? gch : 0) * 4;
+    // one tap per tile (>= 32 gathered channels): the tap offset is wave-uniform -> a scalar register, the lane's channel
+    // offset goes into the common lane term
+    if (NT == 7) goff[t] = __builtin_amdgcn_readfirstlane(((kz * p.hy + ky) * p.hx + kx) * PG);
   }
 
   const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * p.tiles_per_block;
@@ -1525,6 +1529,7 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
     const int nvalid = ok ? (isd ? chd : chg) - ch * 4 : 1; (void)nvalid;                                               \
     okbits |= (unsigned long long)ok << u;                                                                              \
     sv[u] = LD4;                                                                                                        \
+    if (u % 6 == 5) __builtin_amdgcn_sched_barrier(0);   /* bound the live address temporaries: 6 loads per group */      \
   }
   const bool allvec = vecd && vecg;
   auto load_next = [&](int x0, int y0, int z0) __attribute__((always_inline)) {
@@ -1555,7 +1560,7 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
   };
 
   // one voxel pair (2 q, 2 q + 1: x neighbours of one row) -> the lane's dense value and its tiles' gathered values
-  const int lane_d = fh * PD + fr * 4, lane_g = fh * p.stride * PG;
+  const int lane_d = fh * PD + fr * 4, lane_g = fh * p.stride * PG + (NT == 7 ? gch * 4 : 0);
   auto rd = [&](int q, float& d, float (&g)[NT]) {
     const int v = 2 * q;
     const int x = v & (tx - 1), y = (v >> p.lx) & (ty - 1), z = v >> (p.lx + p.ly);
@@ -1932,7 +1937,7 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   if (f32) pl.tn = pl.tc = 1;
   const int gch = d->form == 0 ? x->C : dy->C;
   // bytes per element, channels per piece, 16-byte staging pieces per thread
-  const int esz = f32 ? 4 : 2, ppc = f32 ? 4 : 8, maxp = f32 ? 24 : 20;
+  const int esz = f32 ? 4 : 2, ppc = f32 ? 4 : 8, maxp = f32 ? ((gch >= 32 && d->ksize == 3) ? 21 : 24) : 20;
   // fp32 kernel: the gathered operand's 32 MFMA indices are (tap, channel) pairs -- cp channels (a power of two) per tap
   p.cp = 32; p.pg = 128;
   if (f32 && gch < 32) { p.cp = 1; while (p.cp < gch) p.cp <<= 1; p.pg = (p.cp < 4 ? 4 : p.cp) * 4; }

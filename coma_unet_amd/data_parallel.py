@@ -238,6 +238,7 @@ class StreamedGradExchange:
         self._pending = []
         self._launched = None
         self._forked = False
+        self.early = 0                # buckets of the last step that went out before backward had finished
 
     # -- layout ---------------------------------------------------------------------------------------------------
     def _build(self):
@@ -279,6 +280,7 @@ class StreamedGradExchange:
             self._launched = [False] * len(self._buckets)
         self._pending = []
         self._forked = False
+        self.early = 0
 
     def mark(self, p):
         for i in self._p2b.get(id(p), ()):
@@ -290,6 +292,7 @@ class StreamedGradExchange:
         if self._pending:
             todo, self._pending = self._pending, []
             for i in todo:
+                self.early += not self._launched[i]
                 self._launch(i)
 
     def _launch(self, i):

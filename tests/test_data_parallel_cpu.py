@@ -88,3 +88,117 @@ def test_gloo_world2_gradient_allreduce_matches_global_batch():
         assert p.exitcode == 0
     assert all(r[1] for r in res)
     assert res[0][2] == res[1][2], "broadcast_module must make the replicas identical"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# StreamedGradExchange (the sink-driven, capturable exchange of the C-ABI RCCL path) with the torch.distributed stand-in
+# communicator, plain and sharded; global-batch RnC through gather_batch
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_adamw(p, g, m, v, lr, b1, b2, eps, wd, step, step_dev=None):
+    """torch.optim.AdamW's update on flat views (the HIP kernel's arithmetic, for the CPU-only test)."""
+    p.mul_(1 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt().add_(eps), value=-lr)
+
+
+def _worker_streamed(rank, world, port, q, sharded):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coma_unet_amd import ops
+    from coma_unet_amd.optim import FusedAdamW
+    from coma_unet_amd.data_parallel import StreamedGradExchange, TorchComm, broadcast_module
+    ops.adamw_ = _cpu_adamw                      # (no HIP kernel on the CPU box)
+    torch.manual_seed(7)
+    net, ref = _Net(), _Net()
+    broadcast_module(net, src=0)
+    ref.load_state_dict(net.state_dict())
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2)
+    opt = FusedAdamW(net.parameters(), lr=1e-2, write_through=True, pad_to=world)
+    ex = StreamedGradExchange(opt, TorchComm(), bucket_bytes=128, sharded=sharded)
+    ok = True
+    for step in range(5):
+        g = torch.Generator().manual_seed(50 + step)
+        xs = [torch.randn((4, 7), generator=g) for _ in range(world)]
+        opt.zero_grad()
+        ex.begin()
+        net(xs[rank]).sum().backward()
+        if step >= 1:
+            # stand-in for the backward kernels' write-through: every flat parameter's slot is announced in reverse
+            # order, so buckets complete and go out while "backward" is still running
+            for p in reversed(opt._flat_params):
+                ops.GradSink.slot(p)
+            ops.GradSink.slot(None)
+            ok &= ex._buckets is not None and len(ex._buckets) > 1 and any(ex._launched)
+        stepped = ex.finish()
+        if not stepped:
+            opt.step()
+        ok &= (stepped is True) == (sharded and step >= 1)
+        ropt.zero_grad()
+        ref(torch.cat(xs)).sum().backward()
+        ropt.step()
+        for (n, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
+            ok &= bool(torch.allclose(a, b, rtol=1e-4, atol=1e-6))
+    if sharded:
+        ok &= opt.flat_p.numel() % world == 0
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+def test_gloo_world2_streamed_exchange_matches_global_batch_adamw(sharded):
+    """5 AdamW steps of 2 replicas (bucketed exchange launched from the gradient sink; sharded: reduce-scatter + AdamW on
+    the rank's slices + parameter all-gather) must track torch.optim.AdamW on the global batch."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_streamed, args=(r, world, port, q, sharded)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=60) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
+def _worker_rnc(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coma_unet_amd.criterions import RnCLoss
+    from coma_unet_amd.data_parallel import gather_batch
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn((6, 16), generator=g)
+    labels = torch.rand((6, 6), generator=g)
+    w = torch.randn((16, 16), generator=g).requires_grad_(True)       # a "model" shared by the replicas
+    mine = slice(rank * 3, rank * 3 + 3)
+    f_local = feats[mine] @ w
+    loss = RnCLoss()(gather_batch(f_local), gather_batch(labels[mine].contiguous()))
+    loss.backward()
+    dist.all_reduce(w.grad, op=dist.ReduceOp.SUM)                       # the data-parallel SUM of parameter gradients
+    w2 = w.detach().clone().requires_grad_(True)
+    ref = RnCLoss()(feats @ w2, labels)
+    ref.backward()
+    ok = torch.allclose(loss, ref, rtol=1e-5, atol=1e-6) and torch.allclose(w.grad, w2.grad, rtol=1e-4, atol=1e-6)
+    local_only = RnCLoss()(f_local.detach(), labels[mine])
+    q.put((rank, bool(ok), float(loss), float(local_only)))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_global_batch_rnc_equals_single_process():
+    """forward_loss(..., global_rnc=True): RnC on the all-gathered features equals the single-process loss on the global
+    batch, and the SUM-reduced parameter gradient equals the single-process gradient (per-replica RnC does not)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_rnc, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert abs(res[0][2] - res[0][3]) > 1e-3       # the per-replica value is a different number: the gather matters

@@ -243,6 +243,60 @@ def test_rccl_reducer_path_single_rank():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("sharded", [False, True])
+def test_capi_rccl_exchange_eager_and_in_graph_single_rank(sharded):
+    """The C-ABI RCCL path (coma_comm_init / coma_allreduce_sum_f32 / reduce_scatter + all_gather on a side HIP stream,
+    launched from the gradient sink while backward is still running) with a 1-rank communicator: the reductions are
+    identities, so eager and hipGraph-captured steps -- the graph then CONTAINS the collectives, the fork / join and the
+    (sharded) optimizer step -- must follow the plain single-GPU trajectory."""
+    import coma_unet_amd as cu
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, make_optimizer, GraphedTrainStep
+    from coma_unet_amd.data_parallel import StreamedGradExchange
+    from coma_unet_amd.rccl_comm import RcclComm
+    S = (32, 32, 32)
+    b = make_batch(2, S, seed=61)
+    comm = RcclComm()
+    assert comm.world == 1 and comm.rank == 0
+    t = torch.arange(10, dtype=torch.float32, device="cuda")
+    comm.all_reduce_(t), comm.broadcast_(t)
+    r = torch.empty(10, device="cuda")
+    comm.reduce_scatter(t, r), comm.all_gather(r, t)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(10, dtype=torch.float32))
+
+    def run(mode):
+        torch.manual_seed(4)
+        gm = cu.build_model(volume_shape=S, static_prompts=True, compute_dtype=torch.bfloat16).cuda()
+        gm.set_save_attn(None)
+        gm.train(True)
+        gb = _gpu_batch(b)
+        gb["roi_pred_dicts"] = gm._priors(b["roi_pred_dicts"], 2, torch.device("cuda"))
+        opt = make_optimizer(gm, 1e-5)
+        crit = cu.build_reference_criterion()
+        ex = StreamedGradExchange(opt, comm, bucket_bytes=8 << 20, sharded=sharded) if mode != "plain" else None
+        if mode == "graph":
+            step = GraphedTrainStep(gm, crit, opt, gb, warmup=2, reducer=ex)
+            assert step.in_graph
+            ls = [float(step()[0][0]) for _ in range(3)]
+        else:
+            ls = [float(train_step(gm, crit, opt, gb, ex)[0][0]) for _ in range(5)][2:]
+        if ex is not None:
+            assert ex._buckets is not None and len(ex._buckets) > 4 and all(ex._launched)
+            assert ex.early >= len(ex._buckets) // 2, (ex.early, len(ex._buckets))      # most buckets left before backward ended
+        torch.cuda.synchronize()
+        return ls, opt._flat_step
+
+    plain, n0 = run("plain")
+    eager, n1 = run("eager")
+    graph, n2 = run("graph")
+    print("plain", plain, "capi eager", eager, "capi graph", graph)
+    assert n0 == n1 == n2 == 5
+    for a, g_, r_ in zip(eager, graph, plain):
+        assert abs(a - r_) <= 2e-2 * abs(r_) and abs(g_ - r_) <= 2e-2 * abs(r_)
+    comm.close()
+
+
 def test_graphed_step_matches_eager_steps():
     """The hipGraph-captured step (bench.py's one-GPU launch mode) must walk the same loss trajectory as eager steps.
     Learning rate 1e-5: at 1e-3 two runs of the SAME mode already differ by ~3-8 % after two steps (bf16 + fp32-atomic
