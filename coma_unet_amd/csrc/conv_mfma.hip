@@ -1589,16 +1589,60 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
     __syncthreads();
     if (nt < tile_end) load_next(ntix << p.lx, ntiy << p.ly, ntiz << p.lz);
     float dA, dB, gA[NT], gB[NT];
-    rd(ps, dA, gA);
-    for (int q = ps; q < npairs; q += 2 * ws) {
-      rd(q + ws, dB, gB);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(dA, gA);
-      __builtin_amdgcn_sched_barrier(0);
-      rd(q + 2 * ws < npairs ? q + 2 * ws : ps, dA, gA);        // (the last step re-reads pair `ps`: harmless, keeps the loop uniform)
-      __builtin_amdgcn_sched_barrier(0);
-      mm(dB, gB);
-      __builtin_amdgcn_sched_barrier(0);
+    const int prow = tx >> 1, nrows = TM >> p.lx;            // voxel pairs per x row, rows per tile
+    if (prow >= 2 && (nrows % ws) == 0) {
+      // Row walk: inside a row of the tile consecutive pairs are a constant step apart in both LDS images, so the whole
+      // per-pair address arithmetic is one v_add per read.  (PMC on the per-pair (x, y, z) decomposition this replaces:
+      // 5 VALU + 3 SALU per MFMA, issued in a clump behind each group of MFMAs where only one 64-cycle MFMA shadow
+      // covers them -- 55 % MFMA-pipe occupancy against 76 % for the forward kernel.)
+      const int gstep = 2 * p.stride * PG;
+      for (int r = ps; r < nrows; r += ws) {
+        const int y = r & (ty - 1), z = r >> p.ly;
+        const char* dp = Dt + (r << p.lx) * PD + lane_d;
+        const char* gp[NT];
+        const char* g0 = Gt + ((z * p.stride * p.hy + y * p.stride) * p.hx) * PG + lane_g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gp[t] = g0 + goff[t];
+        auto rdr = [&](float& d, float (&g)[NT]) __attribute__((always_inline)) {
+          d = *reinterpret_cast<const float*>(dp);
+          dp += 2 * PD;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) { g[t] = *reinterpret_cast<const float*>(gp[t]); gp[t] += gstep; }
+        };
+        auto half = [&](float dc, const float (&gc)[NT], float& dn, float (&gn)[NT]) __attribute__((always_inline)) {
+          dn = *reinterpret_cast<const float*>(dp);
+          dp += 2 * PD;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            gn[t] = *reinterpret_cast<const float*>(gp[t]);
+            gp[t] += gstep;
+            __builtin_amdgcn_sched_barrier(0);
+            if (FORM == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc, gc[t], acc[t], 0, 0, 0);
+            else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[t], dc, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        rdr(dA, gA);
+        for (int i = 0; i < prow; i += 2) {
+          // each half step = the NEXT pair's reads + this pair's MFMAs, strictly alternating (read t, MFMA t): every read
+          // and its pointer step issue in the 64-cycle shadow of the previous MFMA, and every MFMA's operand was read a
+          // whole half step earlier (hipcc alone either sinks each read to its MFMA or clumps all of them behind the group)
+          half(dA, gA, dB, gB);
+          half(dB, gB, dA, gA);   // (after the row's last pair this reads one pair past the row -- inside the LDS allocation,
+        }                         //  which carries a 1 KB tail for it -- and is never used: no branch in the loop)
+      }
+    } else {
+      rd(ps, dA, gA);
+      for (int q = ps; q < npairs; q += 2 * ws) {
+        rd(q + ws, dB, gB);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(dA, gA);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(q + 2 * ws < npairs ? q + 2 * ws : ps, dA, gA);        // (the last step re-reads pair `ps`: harmless, keeps the loop uniform)
+        __builtin_amdgcn_sched_barrier(0);
+        mm(dB, gB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     tile = nt; tix = ntix; tiy = ntiy; tiz = ntiz;
   }
@@ -1957,7 +2001,7 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
     p.lx = lx; p.ly = ly; p.lz = lz;
     pl.TM = 1 << (lx + ly + lz);
     p.hz = ((1 << lz) - 1) * p.stride + p.k; p.hy = ((1 << ly) - 1) * p.stride + p.k; p.hx = ((1 << lx) - 1) * p.stride + p.k;
-    pl.lds = (size_t)pl.TM * cdb * esz + (size_t)p.hz * p.hy * p.hx * cgb * esz;
+    pl.lds = (size_t)pl.TM * cdb * esz + (size_t)p.hz * p.hy * p.hx * cgb * esz + (f32 ? 1024 : 0);
     fits = pl.lds <= 160 * 1024 && pl.TM * (cdb / ppc) + p.hz * p.hy * p.hx * (cgb / ppc) <= 256 * maxp;
   }
   if (!fits) return pl;
