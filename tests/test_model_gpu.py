@@ -344,7 +344,10 @@ def test_write_through_gradients_equal_autograd_accumulation():
     grads, nbt = [], []
     for wt in (False, True):
         torch.manual_seed(5)
-        gm = cu.build_model(volume_shape=S, static_prompts=True).cuda()
+        # conv_algo=1: the direct kernels (no split-K / replica atomics in the forward pass), so that the two runs differ by
+        # the gradient plumbing under test only -- with the fp32 MFMA kernels' order-dependent merges an ill-conditioned
+        # scalar (a PReLU slope at the 4^3 level) moves by several per cent from run to run in EITHER mode
+        gm = cu.build_model(volume_shape=S, static_prompts=True, conv_algo=1).cuda()
         gm.set_save_attn(None)
         gm.train(True)
         gb = _gpu_batch(b)
