@@ -1589,54 +1589,20 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
     __syncthreads();
     if (nt < tile_end) load_next(ntix << p.lx, ntiy << p.ly, ntiz << p.lz);
     float dA, dB, gA[NT], gB[NT];
-    const int prow = tx >> 1, nrows = TM >> p.lx;            // voxel pairs per x row, rows per tile
-    if (prow >= 2 && (nrows % ws) == 0) {
-      // Row walk: inside a row of the tile consecutive pairs are a constant step apart in both LDS images, so the whole
-      // per-pair address arithmetic is one v_add per read.  (PMC on the per-pair (x, y, z) decomposition this replaces:
-      // 5 VALU + 3 SALU per MFMA, issued in a clump behind each group of MFMAs where only one 64-cycle MFMA shadow
-      // covers them -- 55 % MFMA-pipe occupancy against 76 % for the forward kernel.)
-      const int gstep = 2 * p.stride * PG;
-      for (int r = ps; r < nrows; r += ws) {
-        const int y = r & (ty - 1), z = r >> p.ly;
-        const char* dp = Dt + (r << p.lx) * PD + lane_d;
-        const char* gp[NT];
-        const char* g0 = Gt + ((z * p.stride * p.hy + y * p.stride) * p.hx) * PG + lane_g;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) gp[t] = g0 + goff[t];
-        auto rdr = [&](float& d, float (&g)[NT]) __attribute__((always_inline)) {
-          d = *reinterpret_cast<const float*>(dp);
-          dp += 2 * PD;
-#pragma unroll
-          for (int t = 0; t < NT; ++t) { g[t] = *reinterpret_cast<const float*>(gp[t]); gp[t] += gstep; }
-        };
-        rdr(dA, gA);
-        for (int i = 0; i < prow; i += 2) {
-          // one pair ahead: the next pair's 8 reads (+ their pointer steps) go out in one group behind this pair's MFMAs.
-          // (Measured alternatives: strictly alternating read / MFMA -- every read in the shadow of the previous MFMA --
-          // ran the 32 -> 32 layer at 57 TFLOP/s against 79 for the grouped order; hipcc's own order sinks every read to its
-          // MFMA and waits lgkmcnt(0).)
-          rdr(dB, gB);
-          __builtin_amdgcn_sched_barrier(0);
-          mm(dA, gA);
-          __builtin_amdgcn_sched_barrier(0);
-          rdr(dA, gA);       // (after the row's last pair this reads one pair past the row -- inside the LDS allocation, which
-          __builtin_amdgcn_sched_barrier(0);     //  carries a 1 KB tail for it -- and is never used: no branch in the loop)
-          mm(dB, gB);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    } else {
-      rd(ps, dA, gA);
-      for (int q = ps; q < npairs; q += 2 * ws) {
-        rd(q + ws, dB, gB);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(dA, gA);
-        __builtin_amdgcn_sched_barrier(0);
-        rd(q + 2 * ws < npairs ? q + 2 * ws : ps, dA, gA);        // (the last step re-reads pair `ps`: harmless, keeps the loop uniform)
-        __builtin_amdgcn_sched_barrier(0);
-        mm(dB, gB);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    // one pair ahead: the next pair's reads go out in one group behind this pair's MFMAs.  Measured alternatives on the
+    // 32 -> 32 layer at 128^3 (this order: 79-82 TFLOP/s): a row walk with one v_add per read instead of the (x, y, z)
+    // decomposition per pair 62-65; reads strictly alternating with the MFMAs 57-59; hipcc's own order (every read sunk to
+    // its MFMA behind lgkmcnt(0)) 70.
+    rd(ps, dA, gA);
+    for (int q = ps; q < npairs; q += 2 * ws) {
+      rd(q + ws, dB, gB);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(dA, gA);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(q + 2 * ws < npairs ? q + 2 * ws : ps, dA, gA);        // (the last step re-reads pair `ps`: harmless, keeps the loop uniform)
+      __builtin_amdgcn_sched_barrier(0);
+      mm(dB, gB);
+      __builtin_amdgcn_sched_barrier(0);
     }
     tile = nt; tix = ntix; tiy = ntiy; tiz = ntiz;
   }

@@ -14,6 +14,21 @@ import os
 import sys
 
 
+def norm_name(k):
+    """rocprofv3 leaves names with a __bf16 template argument mangled: spell every kernel the way the library's
+    coma_last_kernel() does ("conv_mfma_halo2_k<2, 32, 1, 1, __bf16>")."""
+    import re
+    k = k.strip()
+    m = re.match(r"_Z\d+([A-Za-z0-9_]+?)I((?:Li\d+E|DF16b|f|Lb[01]E)+)E", k)
+    if m:
+        args = []
+        for t in re.findall(r"Li(\d+)E|(DF16b)|(f)|Lb([01])E", m.group(2)):
+            args.append(t[0] or ("__bf16" if t[1] else "float" if t[2] else t[3]))
+        return f"{m.group(1)}<{', '.join(args)}>"
+    k = k.replace("void ", "")
+    return k.split("(")[0]
+
+
 def main():
     args = sys.argv[1:]
     match, tj, dirs = None, None, []
@@ -45,7 +60,7 @@ def main():
             if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
                 f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024 * 2.0
                 w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
-                name = k.replace("void ", "").split("(")[0]
+                name = norm_name(k)
                 out[name] = {"hbm_bytes_per_launch": f + w, "fetch_bytes": f, "write_bytes": w,
                              "launches": len(cs["FETCH_SIZE"]), "note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024"}
         json.dump(out, open(tj, "w"), indent=1, sort_keys=True)
