@@ -1,20 +1,26 @@
-import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
-nsteps = int(sys.argv[2])
-agg = collections.defaultdict(list)
-tot = 0
-for r in rows:
-    name = r['Kernel_Name']
-    d = (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
-    tot += d
-    key = (name[:70], r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])
-    agg[key].append(d)
-print(f"total kernel time per step: {tot/nsteps/1e3:.2f} ms")
-byname = collections.defaultdict(float)
-for k, v in agg.items(): byname[k[0]] += sum(v)
-print("--- by kernel name (ms/step) ---")
-for k, v in sorted(byname.items(), key=lambda kv: -kv[1])[:22]:
-    print(f"{v/nsteps/1e3:8.3f}  {k}")
-print("--- top launches ---")
-for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:int(sys.argv[3]) if len(sys.argv)>3 else 25]:
-    print(f"{sum(v)/nsteps:9.1f} us/step  n/step={len(v)/nsteps:4.1f} avg={sum(v)/len(v):8.1f}us  {k}")
+"""Per-kernel summary of a rocprofv3 --kernel-trace csv: launches, average duration, ms per step.
+
+    python profiles/trace_summary.py <kernel_trace.csv> <steps traced>   (steps = warm-up + eager + replayed steps of the run)
+"""
+import collections
+import csv
+import sys
+
+from pmc_summary import norm_name
+
+
+def main():
+    path, steps = sys.argv[1], float(sys.argv[2])
+    acc = collections.defaultdict(list)
+    with open(path, newline="") as fh:
+        for r in csv.DictReader(fh):
+            acc[norm_name(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+    tot = sum(sum(v) for v in acc.values())
+    print(f"total kernel time {tot / 1e3:.2f} ms over {steps:g} steps = {tot / 1e3 / steps:.2f} ms per step; {sum(len(v) for v in acc.values()) / steps:.0f} launches per step")
+    print(f"{'ms/step':>9s} {'n/step':>7s} {'avg us':>9s}  kernel")
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        print(f"{sum(v) / 1e3 / steps:9.3f} {len(v) / steps:7.1f} {sum(v) / len(v):9.1f}  {k[:110]}")
+
+
+if __name__ == "__main__":
+    main()
