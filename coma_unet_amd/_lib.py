@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcoma_unet.so")
+LIB_PATH = os.environ.get("COMA_UNET_LIB") or os.path.join(_HERE, "libcoma_unet.so")   # (override: diagnostic builds, profiles/stamps_halo2.py)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY, ACT_SIGMOID, ACT_PRELU_RELU = range(6)

@@ -464,6 +464,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_halo_k(HaloP p) {
 // PMC on the first halo kernel showed 16 VALU + 4 SALU instructions per MFMA and 54 % of wave
 // cycles waiting; this structure brings the instruction mix under 2 VALU per MFMA.
 // =====================================================================================
+// ---- diagnostic build only (-DCOMA_STAMPS; profiles/stamps_halo2.py): per-phase s_memtime sums of conv_mfma_halo2_k.
+// The stamps leave the kernel through g_stamps alone (no output value depends on them); the shipped library has none.
+#ifdef COMA_STAMPS
+__device__ unsigned long long g_stamps[16];
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(var) const unsigned long long var = stamp_now()
+#define STAMP_ADD(slot, a, b) st_acc[slot] += (b) - (a)
+extern "C" int coma_debug_read_stamps(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, a, b)
+#endif
+
 struct Halo2P {
   const void* x; int ldx; long sbx; int D, H, W, C;
   void* y; int ldy; long sby; int N;
@@ -590,6 +613,10 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   load_halo(tiz * TZ, tiy * TY, tix * TX, 0);
   if (RESIDENT != 1) load_w(0, 0);
 
+#ifdef COMA_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long st_begin = stamp_now();
+#endif
   const bool has_bias = p.bias != nullptr, do_stats = p.stats != nullptr;
   float bv[4][4];
   float st_s[4][4], st_q[4][4];     // fused norm statistics of this lane's 16 channels (stored values)
@@ -618,15 +645,25 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
     }
 
     for (int cc = 0; cc < nchunks; ++cc) {
+      STAMP(t0);
       __syncthreads();                       // all waves finished reading the previous halo / weights
+      STAMP(t1);
+#ifdef COMA_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (diagnostic: how long the prefetched pieces still need)
+#endif
+      STAMP(t1b);
       store_halo(cc * CK);
       if (RESIDENT) {
         if (RESIDENT == 2) store_w();        // this chunk's 27 taps (fetched while the previous chunk / tile was computed)
+        STAMP(t2);
         __syncthreads();
+        STAMP(t3);
         if (RESIDENT == 2) {                 // next chunk of this tile, or chunk 0 of the next tile: a whole chunk of MFMAs to land
           if (cc + 1 < nchunks) { load_w(cc * CK + CK, 0); load_halo(z0, y0, x0, cc * CK + CK); }
           else if (has_next) { load_w(0, 0); load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0); }
         } else if (has_next) load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0);
+        STAMP(t4);
+        STAMP_ADD(0, t0, t1); STAMP_ADD(1, t1, t1b); STAMP_ADD(2, t1b, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4);
         // LDS fragments are read one tap ahead into a second register set (hipcc otherwise issues each ds_read right
         // before the MFMA that consumes it and waits lgkmcnt(0): the full LDS latency on every MFMA at 1-2 waves/SIMD)
         uint4 wv[2][KS], xv[2][2][KS];
@@ -653,6 +690,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
             }
           __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(t5);
+        STAMP_ADD(5, t4, t5);
       } else {
 #pragma unroll 1
         for (int g = 0; g < 3; ++g) {
@@ -688,6 +727,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
       }
     }
     // ---- epilogue: lane = one voxel, 4 groups of 4 consecutive channels ----
+    STAMP(t6);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int j = wid * 2 + i;
@@ -797,8 +837,20 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
         }
       }
     }
+    STAMP(t7);
+    STAMP_ADD(6, t6, t7);
     id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
   }
+#ifdef COMA_STAMPS
+  {
+    const unsigned long long st_end = stamp_now();
+    if (lane == 0 && RESIDENT == 2 && !F32) {
+      for (int k = 0; k < 7; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
+      atomicAdd(&g_stamps[7], st_end - st_begin);
+      atomicAdd(&g_stamps[8], 1ull);
+    }
+  }
+#endif
   // ---- fused statistics: lanes -> wave (butterfly over the 32 voxel lanes) -> block (LDS) -> partial[chunk] ----
   if (p.stats) {
     __syncthreads();                                  // LDS images are dead; reuse the front as a [4 waves][32 ch][2] table
