@@ -494,6 +494,7 @@ struct Halo2P {
   const float* bias; int bsb;
   int flip, vecx, vecw;
   int ntx, nty, ntz, ids_total, ids_per_block;
+  unsigned xbytes, wbytes;   // bytes of one sample of x / of one weight set (buffer descriptors: out-of-range pieces read as zero)
   int st8;             // output rows allow aligned 8-byte (4-channel) stores
   int st16;            // ... and aligned 16-byte (8-channel) stores
   double2* stats;      // optional: per-block {sum, sumsq} of the stored outputs, [chunk][G][N]
@@ -545,6 +546,24 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
     w_goff[it] = (piece < WP && n0 + n < p.N) ? (n0 + n) * p.C + ch * EPB : -1;   // + wtap*N*C + c0 at load time
     w_lds[it] = (t * 32 + n) * P + ch * 16;
   }
+  // VEC: staging goes through buffer loads -- one descriptor per operand, 32-bit byte offsets, the hardware range check
+  // zero-fills an out-of-range piece.  A piece outside the volume gets an out-of-range offset by ONE select: no branch,
+  // no exec masking, no zero-initialised destination, no 64-bit address arithmetic.  (Stamped build of the 64 -> 32
+  // forward at 128^3: issuing a chunk's 27 conditional 64-bit loads took 2400 cycles, 22 % of the kernel, next to 3860 for
+  // its 108 MFMAs.)  The weights' offsets are tile independent: tap, row and flip are folded in once per kernel.
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, VEC ? p.xbytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wb), 0, VEC ? p.wbytes : 0, 0x00020000);
+  constexpr unsigned OOB = 0x7fff0000u;
+  unsigned w_boff[WIT];
+  if constexpr (VEC) {
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int piece = tid + 256 * it;
+      const int t = piece / (CPR * 32);
+      const int wt = p.flip ? 26 - t : t;
+      w_boff[it] = (w_goff[it] >= 0 && t < 27) ? (unsigned)((wt * p.N * p.C + w_goff[it]) * (int)sizeof(T)) : OOB;
+    }
+  }
   // fragment read bases
   int a_base[2];   // voxel operand (MFMA B): this lane's voxel row in each of the wave's two M-tiles
 #pragma unroll
@@ -558,6 +577,18 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   auto load_halo = [&](int z0, int y0, int x0, int c0) {
     const int zb = z0 - 1, yb0 = y0 - 1, xb0 = x0 - 1;
     const long org = ((long)(zb * p.H + yb0) * p.W + xb0) * p.ldx + c0;
+    if constexpr (VEC) {
+      const unsigned org_b = (unsigned)(org * (long)sizeof(T));   // (mod 2^32; negative at the volume's faces: a valid piece's sum is its true offset)
+#pragma unroll
+      for (int it = 0; it < HIT; ++it) {
+        const bool ok = (unsigned)(zb + h_z[it]) < (unsigned)p.D && (unsigned)(yb0 + h_y[it]) < (unsigned)p.H &&
+                        (unsigned)(xb0 + h_x[it]) < (unsigned)p.W;
+        const unsigned voff = ok ? org_b + (unsigned)h_roff[it] * (unsigned)sizeof(T) : OOB;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, 0, 0);
+        hreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
       const bool ok = (unsigned)(zb + h_z[it]) < (unsigned)p.D && (unsigned)(yb0 + h_y[it]) < (unsigned)p.H &&
@@ -577,6 +608,15 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
       }
   };
   auto load_w = [&](int c0, int g) {     // RESIDENT: all 27 taps (g ignored); else kz-plane g
+    if constexpr (VEC && RESIDENT != 0) {
+      const int c0_b = c0 * (int)sizeof(T);               // (chunk offset: a scalar)
+#pragma unroll
+      for (int it = 0; it < WIT; ++it) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_boff[it], c0_b, 0);
+        wreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
       const int piece = tid + 256 * it;
@@ -1031,7 +1071,7 @@ bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const co
 static bool f32_halo_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (x->W < 16 && x->C % 32 == 0 && y->C % 32 == 0) return false;       // 8^3 grids: gather + split-K (as bf16)
   return d->ksize == 3 && d->stride == 1 && x->W >= 8 && (long)x->H * x->W >= 32 && x->C % 16 == 0 && y->C >= 16 &&
-         x->ld % 4 == 0 && x->sb % 4 == 0 && (!x->data || aligned16(x->data));
+         x->ld % 4 == 0 && x->sb % 4 == 0 && (!x->data || aligned16(x->data)) && (unsigned long long)t_vox(x) * x->ld * 4 < 0x7fff0000ull;
 }
 bool conv_f32mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (x->dtype != COMA_F32 || y->dtype != COMA_F32) return false;
@@ -1130,13 +1170,19 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
   p.vecw = x->C % EPB == 0 && aligned16(wk);
   const bool thin = !F32 && x->C <= 16;
   const int lx = x->W >= 32 ? 5 : (x->W >= 16 ? 4 : 3);
-  const bool vec = p.vecx && p.vecw && x->C % (4 * EPB) == 0;
+  // (vector path: buffer loads with 32-bit byte offsets below the out-of-range marker 0x7fff0000)
+  const bool vec = p.vecx && p.vecw && x->C % (4 * EPB) == 0 && (unsigned long long)t_vox(x) * x->ld * sizeof(T) < 0x7fff0000ull;
   if (F32) COMA_CHECK(vec, "conv_mfma(fp32): operands must allow 16-byte channel pieces (C %% 16 == 0, aligned)");
   if (lx == 5 && (thin || vec)) {
     Halo2P q;
     q.x = p.x; q.ldx = p.ldx; q.sbx = p.sbx; q.D = p.D; q.H = p.H; q.W = p.W; q.C = p.C;
     q.y = p.y; q.ldy = p.ldy; q.sby = p.sby; q.N = p.N; q.w = p.w; q.wsb = p.wsb; q.bias = p.bias; q.bsb = p.bsb;
     q.flip = p.flip; q.vecx = p.vecx; q.vecw = p.vecw;
+    {   // descriptor ranges (one sample / one weight set), capped below the out-of-range marker 0x7fff0000
+      const unsigned long long xb_ = (unsigned long long)t_vox(x) * x->ld * sizeof(T), wb_ = 27ull * y->C * x->C * sizeof(T);
+      q.xbytes = (unsigned)(xb_ < 0x7fff0000ull ? xb_ : 0x7fff0000ull);
+      q.wbytes = (unsigned)(wb_ < 0x7fff0000ull ? wb_ : 0x7fff0000ull);
+    }
     q.stats = nullptr; q.stats_inst = stats_inst;
     q.st8 = y->ld % 4 == 0 && y->sb % 4 == 0 && (((uintptr_t)y->data) & 7) == 0;
     q.st16 = y->ld % EPB == 0 && y->sb % EPB == 0 && (((uintptr_t)y->data) & 15) == 0;
