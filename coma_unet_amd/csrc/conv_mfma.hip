@@ -698,10 +698,40 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
         STAMP(t2);
         __syncthreads();
         STAMP(t3);
-        if (RESIDENT == 2) {                 // next chunk of this tile, or chunk 0 of the next tile: a whole chunk of MFMAs to land
-          if (cc + 1 < nchunks) { load_w(cc * CK + CK, 0); load_halo(z0, y0, x0, cc * CK + CK); }
-          else if (has_next) { load_w(0, 0); load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0); }
-        } else if (has_next) load_halo(ntiz * TZ, ntiy * TY, ntix * TX, 0);
+        // What to prefetch while this chunk computes: the next chunk of this tile, or chunk 0 of the next tile.
+        // VEC: the loads are NOT issued here in one burst -- a CU's vector-memory front end takes a chunk's 110 KB of
+        // requests at ~64 B/clk, i.e. ~2000 cycles during which an in-order wave issues no MFMA (stamped build: 22-25 % of
+        // the kernel) -- but one per tap inside the MFMA loop below, through descriptors whose range is zero when there
+        // is nothing to prefetch (every piece then reads as zero: no branch in the loop).
+        const bool same_tile = RESIDENT == 2 && cc + 1 < nchunks;
+        const bool pref = same_tile || has_next;
+        const int pz = same_tile ? z0 : ntiz * TZ, py = same_tile ? y0 : ntiy * TY, px = same_tile ? x0 : ntix * TX;
+        const int pc0 = same_tile ? cc * CK + CK : 0;
+        if constexpr (!VEC) {
+          if (RESIDENT == 2) { if (pref) { load_w(pc0, 0); load_halo(pz, py, px, pc0); } }
+          else if (has_next) load_halo(pz, py, px, 0);
+        }
+        const __amdgpu_buffer_rsrc_t rs_xp = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, (VEC && pref) ? p.xbytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wb), 0, (VEC && pref && RESIDENT == 2) ? p.wbytes : 0, 0x00020000);
+        const unsigned porg_b = (unsigned)((((long)((pz - 1) * p.H + (py - 1)) * p.W + (px - 1)) * p.ldx + pc0) * (long)sizeof(T));
+        const int pc0_b = pc0 * (int)sizeof(T);
+        auto pref_piece = [&](int t) __attribute__((always_inline)) {      // t: the tap whose MFMAs cover this piece's issue
+          if constexpr (VEC) {
+            if (RESIDENT == 2 && t < WIT) {
+              const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_wp, w_boff[t], pc0_b, 0);
+              wreg[t] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+            const int it = RESIDENT == 2 ? t - WIT : t;
+            if (it >= 0 && it < HIT) {
+              const bool ok = (unsigned)(pz - 1 + h_z[it]) < (unsigned)p.D && (unsigned)(py - 1 + h_y[it]) < (unsigned)p.H &&
+                              (unsigned)(px - 1 + h_x[it]) < (unsigned)p.W;
+              const unsigned voff = ok ? porg_b + (unsigned)h_roff[it] * (unsigned)sizeof(T) : OOB;
+              const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_xp, voff, 0, 0);
+              hreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        };
+        static_assert(!VEC || (RESIDENT == 2 ? WIT + HIT : HIT) <= 27, "one prefetch piece per tap");
         STAMP(t4);
         STAMP_ADD(0, t0, t1); STAMP_ADD(1, t1, t1b); STAMP_ADD(2, t1b, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4);
         // LDS fragments are read one tap ahead into a second register set (hipcc otherwise issues each ds_read right
@@ -720,6 +750,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
           if (t + 1 < 27) rd(t + 1, (t + 1) & 1);
+          pref_piece(t);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
