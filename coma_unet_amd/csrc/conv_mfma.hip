@@ -915,7 +915,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
 #ifdef COMA_STAMPS
   {
     const unsigned long long st_end = stamp_now();
-    if (lane == 0 && RESIDENT == 2 && !F32) {
+    if (lane == 0) {
       for (int k = 0; k < 7; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
       atomicAdd(&g_stamps[7], st_end - st_begin);
       atomicAdd(&g_stamps[8], 1ull);
