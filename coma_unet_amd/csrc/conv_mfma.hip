@@ -877,7 +877,11 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
           }
           const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
           const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+#ifdef COMA_ABLATE_STORE      // (diagnostic build only: the epilogue without its global stores; outputs are wrong)
+          asm volatile("" :: "v"(r0[0]), "v"(r1[0]), "v"(r0[1]), "v"(r1[1]), "v"(vox));
+#else
           if (valid) *reinterpret_cast<uint4*>(vox + 16 * gp) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+#endif
         }
       } else if (gz < p.D && gy < p.H && gx < p.W) {
         bf16_t* dst = yb + ((long)(gz * p.H + gy) * p.W + gx) * p.ldy + n0 + 4 * fh;

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cin", type=int, default=64); ap.add_argument("--cout", type=int, default=32)
 ap.add_argument("--size", type=int, default=128); ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--what", default="fwd")
+ap.add_argument("--define", action="append", default=[], help="extra -D flags of the diagnostic build (e.g. COMA_ABLATE_STORE)")
 a = ap.parse_args()
 out = os.path.join(ROOT, "gpurun_out", "stamps")
 os.makedirs(out, exist_ok=True)
@@ -23,6 +24,8 @@ for s_ in srcs:
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", os.path.join(ROOT, "coma_unet_amd", "csrc", s_), "-o", o]
     if s_ == "conv_mfma.hip":
         cmd.insert(1, "-DCOMA_STAMPS")
+        for d_ in a.define:
+            cmd.insert(1, "-D" + d_)
         procs.append(subprocess.Popen(cmd))
     else:
         src_o = os.path.join(ROOT, "coma_unet_amd", "csrc", s_.replace(".hip", ".o"))
@@ -60,6 +63,12 @@ dbg.coma_debug_read_stamps(buf, 0)
 v = list(buf)
 names = ["top barrier", "vmcnt(0) wait", "LDS stores", "2nd barrier", "load issue", "MFMA loop", "epilogue"]
 tot = v[7]
+import time
+t0 = time.perf_counter()
+for _ in range(10):
+    run()
+torch.cuda.synchronize()
+print(f"wall per launch (stamped build{', ' + ','.join(a.define) if a.define else ''}): {(time.perf_counter() - t0) / 10 * 1e6:.1f} us")
 print(f"{a.what} {a.cin}->{a.cout} at {S}^3 B={a.batch}: {v[8] / N:.0f} waves per launch, {tot / max(v[8], 1):.0f} cycles per wave (stamped build)")
 for n, c in zip(names, v[:7]):
     print(f"  {n:14s} {100.0 * c / tot:5.1f} %   {c / max(v[8], 1):10.0f} cycles per wave")
