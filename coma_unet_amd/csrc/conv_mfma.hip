@@ -1664,13 +1664,12 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
     sv[u] = LD4;                                                                                                        \
     if (u % 6 == 5) __builtin_amdgcn_sched_barrier(0);   /* bound the live address temporaries: 6 loads per group */      \
   }
-  const bool allvec = vecd && vecg;
+  // (vector loads only: the host sends operands without 16-byte aligned rows to the direct kernel.  A second, element-wise
+  //  copy of this unrolled loop took the 7-tile variant to 78 KB -- past the 64 KB instruction cache two CUs share.)
   auto load_next = [&](int x0, int y0, int z0) __attribute__((always_inline)) {
     const int bz = z0 * p.stride - p.pad, by = y0 * p.stride - p.pad, bx = x0 * p.stride - p.pad;
     okbits = 0;
-    if (allvec) { F32WG_LOAD_LOOP(*reinterpret_cast<const uint4*>(src)) }
-    else { F32WG_LOAD_LOOP(make_uint4(__float_as_uint(src[0]), nvalid > 1 ? __float_as_uint(src[1]) : 0u,
-                                      nvalid > 2 ? __float_as_uint(src[2]) : 0u, nvalid > 3 ? __float_as_uint(src[3]) : 0u)) }
+    F32WG_LOAD_LOOP(*reinterpret_cast<const uint4*>(src))
   };
 #undef F32WG_LOAD_LOOP
   const bool partd = (chd & 3) != 0 && chd < 32, partg = (chg & 3) != 0 && chg < 32;     // a piece with 1..3 valid channels exists
@@ -1741,6 +1740,27 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
   }
   // ---- merge into dwk[b][tap][n][c] ----
   float* wout = p.dwk + (long)b * p.wsb + (long)(blockIdx.x % (unsigned)p.nrep) * p.rep_stride;
+  if constexpr (NT == 7) {
+    // one tap per tile (both forms): row r of the accumulator is output channel n0 + r, the lane's column is input channel
+    // c0 + fr.  One pointer per tile, stepped through the 16 rows (kept compact: the 112 merges of the 7-tile variant
+    // with per-element index arithmetic alone were 13 KB of code)
+    const int c = c0 + fr;
+    const bool full = n0 + 32 <= p.N;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int tap = tg + wt * t;
+      if (tap < ntaps && c < p.C) {
+        float* pe = wout + ((long)tap * p.N + n0 + 4 * fh) * p.C + c;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if (full || n0 + (e & 3) + 8 * (e >> 2) + 4 * fh < p.N) {
+            if (p.plain) *pe = acc[t][e]; else atomicAdd(pe, acc[t][e]);
+          }
+          pe += ((e & 3) == 3 ? 5 : 1) * p.C;
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -1759,6 +1779,7 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad_k(WgradP2 p) {
         else atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, acc[t][e]);
       }
     }
+  }
   }
 }
 
@@ -2078,6 +2099,7 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
   // fp32 kernel: the gathered operand's 32 MFMA indices are (tap, channel) pairs -- cp channels (a power of two) per tap
   p.cp = 32; p.pg = 128;
   if (f32 && gch < 32) { p.cp = 1; while (p.cp < gch) p.cp <<= 1; p.pg = (p.cp < 4 ? 4 : p.cp) * 4; }
+  if (f32 && !(p.vec_n && p.vec_c)) return pl;        // fp32 kernel: 16-byte staging loads only
   // tile: up to 256 dense voxels at stride 1, 64 at stride 2 (the halo grows 8x); shrink until the LDS image
   // and the per-thread register staging budget (20 x 16-byte pieces) fit
   const int cdb = 32 * (d->form == 0 ? pl.tn : pl.tc), cgb = f32 ? p.pg / 4 : 32 * (d->form == 0 ? pl.tc : pl.tn);
