@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly even on one GPU")
+    ap.add_argument("--dp", default=os.environ.get("COMA_DP", "torch"), choices=["torch", "capi", "capi-sharded"],
+                    help="N > 1 gradient exchange: torch = torch.distributed (RCCL) all-reduce after the graph-replayed fwd+bwd; "
+                         "capi = the C-ABI RCCL path (coma_allreduce_sum_f32 on a side stream, launched from the gradient sink "
+                         "while backward runs, captured INSIDE the step graph); capi-sharded = reduce-scatter + AdamW on 1/N + all-gather")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,7 +129,7 @@ def main():
     from coma_unet_amd import ops
     from coma_unet_amd.synthetic import make_batch
     from coma_unet_amd.train import train_step, make_optimizer, GraphedTrainStep
-    from coma_unet_amd.data_parallel import GradReducer, broadcast_module
+    from coma_unet_amd.data_parallel import GradReducer, StreamedGradExchange, broadcast_module
 
     S = (args.size,) * 3
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -136,8 +140,16 @@ def main():
     if world > 1:
         broadcast_module(model)
     crit = cu.build_reference_criterion(dev)
-    opt = make_optimizer(model, 1e-3)
-    reducer = GradReducer(opt) if world > 1 else None
+    opt = make_optimizer(model, 1e-3, pad_to=world if args.dp == "capi-sharded" else 1)
+
+    def make_reducer():
+        if world == 1:
+            return None
+        if args.dp == "torch":
+            return GradReducer(opt)
+        from coma_unet_amd.rccl_comm import RcclComm
+        return StreamedGradExchange(opt, RcclComm(device=dev), sharded=args.dp == "capi-sharded")
+    reducer = make_reducer()
     b = make_batch(args.batch, S, seed=1000 + rank)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
     batch["roi_pred_dicts"] = model._priors(b["roi_pred_dicts"], args.batch, dev)   # (B,36,2) resident table
@@ -162,7 +174,8 @@ def main():
             print(graph_note, file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             use_graph = False
-            reducer = GradReducer(opt) if world > 1 else None
+            args.dp = "torch"                      # the plain, rehearsed path
+            reducer = make_reducer()
     if not use_graph:
         for _ in range(args.warmup):
             train_step(model, crit, opt, batch, reducer)
@@ -236,8 +249,10 @@ def main():
             "config": {"workload": f"CoMA-UNet train step (fwd + RoiMSE/RnC loss + bwd + all-reduce + AdamW), "
                                    f"{args.size}^3 volumes, batch {args.batch}/GPU, 6-dim covariates (BASELINE configs[3])",
                        "global_batch": args.batch * world, "volume": list(S), "parallelism": f"dp{world}",
-                       "launch": ("hipGraph replay" + (" of fwd+bwd, then bucketed RCCL all-reduce + AdamW" if world > 1 else " of the whole step"))
-                                 if use_graph else "eager (hook-driven all-reduce overlap)",
+                       "launch": ("hipGraph replay" + ((" of fwd+bwd, then bucketed RCCL all-reduce + AdamW" if args.dp == "torch" else
+                                                        f" of the whole step incl. the overlapped C-ABI RCCL exchange ({args.dp})")
+                                                       if world > 1 else " of the whole step"))
+                                 if use_graph else "eager (all-reduce overlapped with backward)",
                        "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 1)},
             "loss": round(loss, 4), "note": graph_note,
             "unet_tflops_per_s": round(step_ach, 2),
