@@ -15,5 +15,5 @@ def build_model(volume_shape=(128, 128, 128), compute_dtype=None, **kw):
     """The constructor call of validation.py:98."""
     import torch
     return ContrastiveAttentionUNET_DP(*DEFAULT_MODEL_PARAMS, latent_spaces=[2048] * 5, conditional=True,
-                                       decoder_ds=False, volume_shape=volume_shape,
+                                       decoder_ds=kw.pop("decoder_ds", False), volume_shape=volume_shape,
                                        compute_dtype=compute_dtype or torch.float32, **kw)

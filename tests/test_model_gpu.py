@@ -480,6 +480,62 @@ def test_resume_into_fresh_optimizer_matches_uninterrupted_run(tmp_path):
     assert float(opt3.flat_m.norm()) > 0.5 * m_norm
 
 
+def test_return_branches_embeddings_decoder_ds_save_attn():
+    """The return contracts the training loop never takes (attn_unet_data_parallel.py:147-148, 225-227, 687-691):
+    embeddings_out -> (out, projected, final, encoder features), decoder_ds -> (out, projected, final, []),
+    save_attn -> the gate also returns its coefficients (and the layer still returns the gated features).
+    Outputs must equal the default branch's (same weights, same inputs) and the oracle's shapes."""
+    import coma_unet_amd as cu
+    from coma_unet_amd.synthetic import make_batch
+    from oracle.coma_oracle import build_reference_model
+    S = (32, 32, 32)
+    b = make_batch(2, S, seed=71)
+    gb = _gpu_batch(b)
+    torch.manual_seed(9)
+    base = cu.build_model(volume_shape=S).cuda()
+    base.set_save_attn(None)
+    base.train(True)
+    sd = base.state_dict()
+    with torch.no_grad():
+        ref = base(gb["mri"], gb["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=gb["roi"])
+    assert len(ref) == 3
+
+    def variant(**kw):
+        m = cu.build_model(volume_shape=S, **kw).cuda()
+        m.load_state_dict(sd)
+        m.set_save_attn(None)
+        m.train(True)
+        return m
+
+    with torch.no_grad():
+        emb = variant(embeddings_out=True)
+        o = emb(gb["mri"], gb["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=gb["roi"])
+        assert len(o) == 4 and rel(o[0], ref[0]) < 1e-5 and rel(o[2], ref[2]) < 1e-5
+        assert [tuple(e.shape) for e in o[3]] == [(2, 32, 32, 32, 32), (2, 64, 16, 16, 16), (2, 128, 8, 8, 8), (2, 256, 4, 4, 4), (2, 512, 2, 2, 2)]
+        emb.train(False)        # eval + embeddings_out still returns the 4-tuple (:672-673 only short-cuts without embeddings_out)
+        emb.set_training(False)
+        assert len(emb(gb["mri"], gb["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=gb["roi"])) == 4
+        dds = variant(decoder_ds=True)
+        o = dds(gb["mri"], gb["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=gb["roi"])
+        assert len(o) == 4 and o[3] == [] and rel(o[0], ref[0]) < 1e-5 and dds.decoder_ds
+        sa = variant()
+        sa.set_save_attn("/nonexistent/attention_dump_dir")       # not None: the gates return (att, psi); nothing is written to disk here
+        o = sa(gb["mri"], gb["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=gb["roi"])
+        assert len(o) == 3 and rel(o[0], ref[0]) < 1e-5
+        gate = sa.model[1].attention
+        assert gate.save_attn is not None
+        g = torch.randn((2, 32, 32, 32, 32), device="cuda")
+        x = torch.randn((2, 32, 32, 32, 32), device="cuda")
+        att, psi = gate(g=g, x=x)
+        assert tuple(psi.shape) == (2, 32, 32, 32, 1) and rel(att, x * psi) < 1e-5 and 0.0 < float(psi.min()) and float(psi.max()) < 1.0
+    # the oracle takes the same branches with the same tuple lengths
+    om = build_reference_model(volume_shape=S, embeddings_out=True)
+    om.set_save_attn(None)
+    with torch.no_grad():
+        oo = om(b["mri"], b["covars"], roi_pred_dicts=b["roi_pred_dicts"], sample_roi_mask=b["roi"])
+    assert len(oo) == 4 and [tuple(e.shape) for e in oo[3]] == [(2, 32, 32, 32, 32), (2, 64, 16, 16, 16), (2, 128, 8, 8, 8), (2, 256, 4, 4, 4), (2, 512, 2, 2, 2)]
+
+
 def test_noncubic_volume_odd_batch():
     """Shapes the tiling has to cope with beyond the cubes of the BASELINE configs: a 32 x 48 x 64 volume, batch 3 --
     fp32 forward + loss against the oracle, then bf16 eager and graph-replayed train steps (finite, decreasing)."""
