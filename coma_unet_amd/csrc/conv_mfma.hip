@@ -952,6 +952,291 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
 }
 
 // =====================================================================================
+// conv_thin16_k -- stride-1 3x3x3 convolution (forward, and data-gradient via `flip`) of the few-channel full-resolution
+// layers (C <= 16 input channels, N <= 32 output channels: the prompt / UQ tail 3->16->16->1, 2->8->8->1, the 1->32 head
+// convolution and their data-gradients), W >= 32.  These layers are bandwidth-bound (2 (C + N) bytes per voxel); on the
+// 32x32x16 tiles of conv_mfma_halo2_k they were bound by MFMA time spent on zero padding instead (16 -> 16: half of every
+// tile, 8 -> 8: 7/8).  Here:
+//  * v_mfma_f32_16x16x32_bf16 with the TAPS packed along K: K = 32 = 2 taps x 16 channels (CP = 16) or 4 taps x 8
+//    channels (CP = 8), so a 3x3x3 stencil is 14 or 7 MFMAs per 16 voxels x 16 output channels instead of 27 (x2 padding);
+//  * the weights never touch LDS: NM x NB fragments (<= 56 VGPRs) are loaded once per kernel and stay in registers;
+//  * the lane's B fragment is ONE 16-byte LDS read at `lane base of the MFMA + compile-time voxel-group offset`: the tap a
+//    lane reads is a per-lane constant folded into that base;
+//  * staging through buffer loads (hardware zero fill outside the volume), the next tile's pieces issued one by one
+//    inside the MFMA loop; channels of a wider / padded buffer that are not this tensor's are masked at the LDS store;
+//  * lane = (voxel, 4 consecutive output channels): 8-byte stores, BN / IN statistics out of the epilogue.
+// Tile = 2 x 4 x 32 voxels = 16 groups of 16 voxels, 4 per wave; persistent blocks, 2 per CU.
+// =====================================================================================
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct Thin16P {
+  const bf16_t* x; int ldx; long sbx; int D, H, W, C;
+  bf16_t* y; int ldy; long sby; int N;
+  const bf16_t* w; long wsb;
+  const float* bias; int bsb;
+  int flip;
+  unsigned xbytes;
+  int ntx, nty, ntz, ids_total, ids_per_block;
+  int st8;             // output rows allow aligned 8-byte (4-channel) stores
+  double2* stats; int stats_inst;
+};
+
+template <int CP, int NB>      // CP = padded input channels per tap (16 or 8), NB = 16-channel output blocks (1 or 2)
+__global__ __launch_bounds__(256, 2) void conv_thin16_k(Thin16P p) {
+  constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
+  constexpr int TPM = 32 / CP, NM = (27 + TPM - 1) / TPM;        // taps per MFMA, MFMAs per voxel group
+  constexpr int PCH = CP / 8;                                     // 16-byte pieces per halo row
+  // LDS row pitch = the row itself (32 or 16 bytes): the four 16-lane groups of a ds_read_b128 then each read 16
+  // voxels x 16 bytes out of consecutive rows, which is conflict-free on the 64 x 4-byte banks.  (The 48-byte pitch of the
+  // 32x32x16 kernels made this read 2-way: 16 -> 16 at 128^3 145 us, of which ~80 us was the fragment reads.)
+  constexpr int P = CP * 2;
+  constexpr int HP = HV * PCH, HIT = (HP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Hl = smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z;
+#ifdef COMA_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long st_begin = stamp_now();
+  bool st_first = true;
+#endif
+  const int lv = lane & 15, lg = lane >> 4;                       // voxel within the group / k group (A, B) = row group (D)
+  const bf16_t* xb = p.x + (long)b * p.sbx;
+  const bf16_t* wb = p.w + (long)b * p.wsb;
+  bf16_t* yb = p.y + (long)b * p.sby;
+
+  // ---- weights -> registers: lane (n = lv, k group lg) holds w[tap][nb*16 + n][8 channels] of its tap in each MFMA ----
+  const int tsub = CP == 16 ? lg >> 1 : lg, cofs = CP == 16 ? 8 * (lg & 1) : 0;
+  // The weight tensor (27 N C bf16, <= 14 KB) is copied to LDS once, coalesced, and each lane picks its fragments there
+  // (per-lane 2-byte global loads were 56..112 scattered requests per lane).
+  {
+    const int total = 27 * p.N * p.C;
+    unsigned short* Wl = reinterpret_cast<unsigned short*>(smem);
+    const unsigned short* wg = reinterpret_cast<const unsigned short*>(wb);
+    if ((total & 7) == 0 && (((uintptr_t)wg) & 15) == 0) {
+      for (int i = tid; i < (total >> 3); i += 256) reinterpret_cast<uint4*>(Wl)[i] = reinterpret_cast<const uint4*>(wg)[i];
+    } else {
+      for (int i = tid; i < total; i += 256) Wl[i] = wg[i];
+    }
+  }
+  __syncthreads();
+  bf16x8_t wf[NM][NB];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int tap = m * TPM + tsub;
+    const int wt = p.flip ? 26 - tap : tap;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = nb * 16 + lv;
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cofs + j;
+        const bool ok = tap < 27 && n < p.N && c < p.C;
+        const unsigned short v = reinterpret_cast<const unsigned short*>(smem)[ok ? (wt * p.N + n) * p.C + c : 0];
+        e[j] = ok ? v : (unsigned short)0;
+      }
+      wf[m][nb] = (bf16x8_t){(short)e[0], (short)e[1], (short)e[2], (short)e[3], (short)e[4], (short)e[5], (short)e[6], (short)e[7]};
+    }
+  }
+  // ---- B-fragment bases: this wave's first voxel group, this lane's voxel, its tap in MFMA m, its channel half ----
+  const int gz = wid >> 1, gy0 = 2 * (wid & 1);
+  int abase[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int tap = m * TPM + tsub < 27 ? m * TPM + tsub : 0;       // (padding taps have zero weights: read tap 0)
+    const int kx = tap % 3, ky = (tap / 3) % 3, kz = tap / 9;
+    abase[m] = (((gz + kz) * HY + gy0 + ky) * HX + lv + kx) * P + cofs * 2;
+  }
+  // ---- staging descriptors ----
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xb), 0, p.xbytes, 0x00020000);
+  constexpr unsigned OOB = 0x7fff0000u;
+  int h_z[HIT], h_y[HIT], h_x[HIT], h_lds[HIT];
+  unsigned h_boff[HIT];
+#pragma unroll
+  for (int it = 0; it < HIT; ++it) {
+    const int piece = tid + 256 * it;
+    const int row = piece / PCH, ch = piece % PCH;
+    const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+    h_z[it] = piece < HP ? hz : (1 << 20); h_y[it] = hy; h_x[it] = hx;
+#ifdef COMA_ABLATE_HALO      // (diagnostic: fetch the tile's own voxels only)
+    if (hz < 1 || hz > TZ || hy < 1 || hy > TY || hx < 1 || hx > TX) h_z[it] = 1 << 20;
+#endif
+    h_boff[it] = (unsigned)((((hz * p.H + hy) * p.W + hx) * p.ldx + ch * 8) * 2);
+    h_lds[it] = row * P + ch * 16;
+  }
+  // channels of the row's piece that belong to this tensor (the rest is padding or a neighbour's slice of a wider buffer)
+  const uint4 hmask = mask8(p.C - 8 * (tid % PCH));       // (piece = tid + 256 it: the piece's channel half is a per-thread constant)
+  uint4 hreg[HIT];
+  auto issue = [&](int it, int z0, int y0, int x0) __attribute__((always_inline)) {
+    const bool ok = (unsigned)(z0 - 1 + h_z[it]) < (unsigned)p.D && (unsigned)(y0 - 1 + h_y[it]) < (unsigned)p.H &&
+                    (unsigned)(x0 - 1 + h_x[it]) < (unsigned)p.W;
+    const unsigned org_b = (unsigned)((((long)((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * p.ldx) * 2);
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? org_b + h_boff[it] : OOB, 0, 0);
+    hreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  auto store_halo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it)
+      if (tid + 256 * it < HP) {
+        const uint4 m = hmask;
+        uint4 v = hreg[it];
+        v.x &= m.x; v.y &= m.y; v.z &= m.z; v.w &= m.w;
+        *reinterpret_cast<uint4*>(Hl + h_lds[it]) = v;
+      }
+  };
+
+  const int id_begin = xcd_remap(blockIdx.x, gridDim.x) * p.ids_per_block;
+  int id_end = id_begin + p.ids_per_block;
+  if (id_end > p.ids_total) id_end = p.ids_total;
+  int id = id_begin, tix = 0, tiy = 0, tiz = 0;
+  while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
+  const bool do_stats = p.stats != nullptr;
+  float st_s[NB][4], st_q[NB][4], bv[NB][4];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nb * 16 + 4 * lg + j;
+      st_s[nb][j] = 0.f; st_q[nb][j] = 0.f;
+      bv[nb][j] = (p.bias && n < p.N) ? p.bias[b * p.bsb + n] : 0.f;
+    }
+  if (id < id_end) {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) issue(it, tiz * TZ, tiy * TY, tix * TX);
+  }
+  while (id < id_end) {
+    const int x0 = tix * TX, y0 = tiy * TY, z0 = tiz * TZ;
+    int nid = id + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nid < id_end && !tile_coords(nid, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nid;
+    const bool has_next = nid < id_end;
+    // nothing to prefetch after the last tile: a zero-range descriptor makes every piece read as zero (no branch in the loop)
+    const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xb), 0, has_next ? p.xbytes : 0, 0x00020000);
+    STAMP(t0);
+#ifdef COMA_STAMPS
+    if (st_first) { st_acc[0] += t0 - st_begin; st_first = false; }
+#endif
+    __syncthreads();                       // the previous tile's fragment reads are done
+    STAMP(t1);
+#ifdef COMA_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(t2);
+    store_halo();
+    __syncthreads();
+    STAMP(t3);
+    f32x4_t acc[4][NB];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[q][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // B fragments run two MFMA steps (8 LDS reads) ahead of their use: left to itself the scheduler keeps ONE read in
+    // flight and every 16-cycle MFMA then waits out an LDS round trip.
+    uint4 fr[3][4];
+    auto ldfrag = [&](int m, int q) __attribute__((always_inline)) {
+      return *reinterpret_cast<const uint4*>(Hl + abase[m] + ((q >> 1) * HX + (q & 1) * 16) * P);
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { fr[0][q] = ldfrag(0, q); fr[1][q] = ldfrag(1, q); }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      if (m + 2 < NM) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fr[(m + 2) % 3][q] = ldfrag(m + 2, q);
+      }
+      if (m < HIT) {                       // one staging piece of the next tile per MFMA step
+        const int it = m;
+        const bool ok = (unsigned)(ntiz * TZ - 1 + h_z[it]) < (unsigned)p.D && (unsigned)(ntiy * TY - 1 + h_y[it]) < (unsigned)p.H &&
+                        (unsigned)(ntix * TX - 1 + h_x[it]) < (unsigned)p.W;
+        const unsigned org_b = (unsigned)((((long)((ntiz * TZ - 1) * p.H + (ntiy * TY - 1)) * p.W + (ntix * TX - 1)) * p.ldx) * 2);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_n, ok ? org_b + h_boff[it] : OOB, 0, 0);
+        hreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef COMA_ABLATE_MFMA
+      if (m > 0) continue;
+#endif
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {        // voxel group q of this wave: row gy0 + (q >> 1), x half q & 1
+        const uint4 f = fr[m % 3][q];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[q][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m][nb], *reinterpret_cast<const bf16x8_t*>(&f), acc[q][nb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(HIT <= NM, "one staging piece per MFMA step");
+    STAMP(t4);
+    // ---- epilogue: lane = voxel lv of group q, output channels nb*16 + 4 lg + 0..3 ----
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int vz = z0 + gz, vy = y0 + gy0 + (q >> 1), vx = x0 + (q & 1) * 16 + lv;
+      const bool valid = vz < p.D && vy < p.H && vx < p.W;
+      bf16_t* vox = yb + ((long)(vz * p.H + vy) * p.W + vx) * p.ldy;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = nb * 16 + 4 * lg;
+        if (n >= p.N) continue;
+        bf16_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = static_cast<bf16_t>(acc[q][nb][j] + bv[nb][j]);
+          if (do_stats) { const float r = valid ? static_cast<float>(o[j]) : 0.f; st_s[nb][j] += r; st_q[nb][j] = fmaf(r, r, st_q[nb][j]); }
+        }
+#ifdef COMA_ABLATE_STORE
+        if (valid && acc[q][nb][0] == 123.456f) {
+#else
+        if (valid) {
+#endif
+          if (p.st8 && n + 3 < p.N) *reinterpret_cast<uint2*>(vox + n) = *reinterpret_cast<const uint2*>(o);
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n + j < p.N) vox[n + j] = o[j];
+          }
+        }
+      }
+    }
+    id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
+    STAMP(t5);
+    STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4); STAMP_ADD(5, t4, t5);
+  }
+#ifdef COMA_STAMPS
+  {
+    const unsigned long long st_end = stamp_now();
+    if (lane == 0) {
+      for (int k = 0; k < 7; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
+      atomicAdd(&g_stamps[7], st_end - st_begin);
+      atomicAdd(&g_stamps[8], 1ull);
+    }
+  }
+#endif
+  // ---- fused statistics: the 16 voxel lanes of a row group -> wave -> block (LDS) -> partial[chunk] ----
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [4 waves][32 ch][2]
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = st_s[nb][j], c = st_q[nb][j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+        if (lv == 0) { red[(wid * 32 + nb * 16 + 4 * lg + j) * 2] = a; red[(wid * 32 + nb * 16 + 4 * lg + j) * 2 + 1] = c; }
+      }
+    __syncthreads();
+    if (tid < NB * 16 && tid < p.N) {
+      double a = 0.0, c = 0.0;
+      for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
+      const int G = p.stats_inst ? gridDim.z : 1;
+      const int g = p.stats_inst ? b : 0;
+      const int chunk = p.stats_inst ? blockIdx.x : blockIdx.x + gridDim.x * b;
+      p.stats[((long)chunk * G + g) * p.N + tid] = make_double2(a, c);
+    }
+  }
+}
+
+// =====================================================================================
 // conv_mfma_pw_k -- 1x1x1 convolution for small channel counts (8 <= C <= 64, N <= 64): the attention
 // gate's W_g / W_x (C -> C/2) and their data-gradients at full resolution.  HBM-bound: no LDS at all --
 // the weight fragments live in registers for the whole kernel, each lane streams 16-byte channel chunks
@@ -1208,6 +1493,38 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
   // (vector path: buffer loads with 32-bit byte offsets below the out-of-range marker 0x7fff0000)
   const bool vec = p.vecx && p.vecw && x->C % (4 * EPB) == 0 && (unsigned long long)t_vox(x) * x->ld * sizeof(T) < 0x7fff0000ull;
   if (F32) COMA_CHECK(vec, "conv_mfma(fp32): operands must allow 16-byte channel pieces (C %% 16 == 0, aligned)");
+  if constexpr (!F32) {
+    static const bool thin16_on = []{ const char* e = getenv("COMA_THIN16"); return !(e && e[0] == '0'); }();
+    const unsigned long long xb_ = (unsigned long long)t_vox(x) * x->ld * sizeof(T);
+    if (thin16_on && thin && lx == 5 && y->C <= (x->C > 8 ? 16 : 32) && p.vecx && xb_ < 0x7fff0000ull) {
+      Thin16P q;
+      q.x = (const bf16_t*)p.x; q.ldx = p.ldx; q.sbx = p.sbx; q.D = p.D; q.H = p.H; q.W = p.W; q.C = p.C;
+      q.y = (bf16_t*)p.y; q.ldy = p.ldy; q.sby = p.sby; q.N = p.N; q.w = (const bf16_t*)p.w; q.wsb = p.wsb; q.bias = p.bias; q.bsb = p.bsb;
+      q.flip = p.flip; q.xbytes = (unsigned)xb_;
+      q.st8 = y->ld % 4 == 0 && y->sb % 4 == 0 && (((uintptr_t)y->data) & 7) == 0;
+      q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
+      q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
+      int gx = 1024 / x->B;                              // >= 2 blocks per CU
+      if (gx < 1) gx = 1;
+      if (gx > q.ids_total) gx = q.ids_total;
+      q.ids_per_block = (q.ids_total + gx - 1) / gx;
+      gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
+      q.stats = nullptr; q.stats_inst = stats_inst;
+      if (stats && gx * (stats_inst ? 1 : x->B) <= 1024 / (stats_inst ? x->B : 1)) {
+        q.stats = stats;
+        *stats_chunks = stats_inst ? gx : gx * x->B;
+      }
+      dim3 grid((unsigned)gx, 1, (unsigned)x->B);
+      const bool c16 = q.C > 8, n32 = q.N > 16;
+      size_t lds = (size_t)34 * 6 * 4 * (c16 ? 32 : 16);
+      if (lds < (size_t)27 * q.N * q.C * 2) lds = (size_t)27 * q.N * q.C * 2;     // the weights are staged there first (<= 13.8 KB)
+      coma_set_kernel_tag("conv_thin16_k<%d, %d>", c16 ? 16 : 8, n32 ? 2 : 1);
+      if (c16) hipLaunchKernelGGL((conv_thin16_k<16, 1>), grid, dim3(256), lds, s, q);
+      else     { if (n32) hipLaunchKernelGGL((conv_thin16_k<8, 2>), grid, dim3(256), lds, s, q);  else hipLaunchKernelGGL((conv_thin16_k<8, 1>), grid, dim3(256), lds, s, q); }
+      COMA_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (lx == 5 && (thin || vec)) {
     Halo2P q;
     q.x = p.x; q.ldx = p.ldx; q.sbx = p.sbx; q.D = p.D; q.H = p.H; q.W = p.W; q.C = p.C;

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cin", type=int, default=64); ap.add_argument("--cout", type=int, default=32)
 ap.add_argument("--size", type=int, default=128); ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--what", default="fwd")
+ap.add_argument("--no-stamps", action="store_true", help="diagnostic build with the --define flags only: wall time per launch")
 ap.add_argument("--define", action="append", default=[], help="extra -D flags of the diagnostic build (e.g. COMA_ABLATE_STORE)")
 a = ap.parse_args()
 out = os.path.join(ROOT, "gpurun_out", "stamps")
@@ -23,7 +24,8 @@ for s_ in srcs:
     o = os.path.join(out, s_.replace(".hip", ".o")); objs.append(o)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", os.path.join(ROOT, "coma_unet_amd", "csrc", s_), "-o", o]
     if s_ == "conv_mfma.hip":
-        cmd.insert(1, "-DCOMA_STAMPS")
+        if not a.no_stamps:
+            cmd.insert(1, "-DCOMA_STAMPS")
         for d_ in a.define:
             cmd.insert(1, "-D" + d_)
         procs.append(subprocess.Popen(cmd))
@@ -54,22 +56,28 @@ def run():
 for _ in range(3):
     run()
 torch.cuda.synchronize()
-dbg.coma_debug_read_stamps(buf, 1)
+if not a.no_stamps:
+    dbg.coma_debug_read_stamps(buf, 1)
 N = 5
 for _ in range(N):
     run()
 torch.cuda.synchronize()
-dbg.coma_debug_read_stamps(buf, 0)
+if not a.no_stamps:
+    dbg.coma_debug_read_stamps(buf, 0)
 v = list(buf)
 names = ["top barrier", "vmcnt(0) wait", "LDS stores", "2nd barrier", "load issue", "MFMA loop", "epilogue"]
+if a.cin <= 16 and a.cout <= 32:      # conv_thin16_k's phases
+    names = ["prologue (weights)", "top barrier", "vmcnt(0) wait", "LDS stores + barrier", "MFMA loop (+ prefetch issue)", "epilogue", "-"]
 tot = v[7]
 import time
 t0 = time.perf_counter()
 for _ in range(10):
     run()
 torch.cuda.synchronize()
-print(f"wall per launch (stamped build{', ' + ','.join(a.define) if a.define else ''}): {(time.perf_counter() - t0) / 10 * 1e6:.1f} us")
+print(f"wall per launch ({'diagnostic' if a.no_stamps else 'stamped'} build{', ' + ','.join(a.define) if a.define else ''}): {(time.perf_counter() - t0) / 10 * 1e6:.1f} us")
+if a.no_stamps:
+    sys.exit(0)
 print(f"{a.what} {a.cin}->{a.cout} at {S}^3 B={a.batch}: {v[8] / N:.0f} waves per launch, {tot / max(v[8], 1):.0f} cycles per wave (stamped build)")
 for n, c in zip(names, v[:7]):
-    print(f"  {n:14s} {100.0 * c / tot:5.1f} %   {c / max(v[8], 1):10.0f} cycles per wave")
+    print(f"  {n:30s} {100.0 * c / tot:5.1f} %   {c / max(v[8], 1):10.0f} cycles per wave")
 print(f"  {'other':14s} {100.0 * (tot - sum(v[:7])) / tot:5.1f} %")

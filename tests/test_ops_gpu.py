@@ -544,3 +544,72 @@ def test_thin_conv_on_padded_pitch_buffers_masks_foreign_lanes(cin, cout):
     y.backward(padded(gy))
     assert torch.isfinite(xi.grad.float()).all() and rel(to_ext(xi.grad), xr.grad) < 8e-3
     assert torch.isfinite(mg.grad).all() and rel(mg.grad, wr.grad) < 8e-3
+
+
+THIN16_CASES = [
+    # cin, cout, dims, per_sample       (W >= 32: conv_thin16_k; ragged in every direction; several tiles per block)
+    (16, 16, (5, 9, 37), False), (16, 16, (4, 6, 70), True), (8, 8, (6, 7, 40), False), (16, 1, (3, 5, 33), False),
+    (8, 1, (5, 4, 32), False), (3, 16, (4, 6, 35), False), (2, 8, (3, 4, 40), True), (1, 32, (6, 9, 37), False),
+    (16, 3, (4, 5, 36), False), (1, 16, (7, 8, 45), False), (8, 2, (4, 4, 33), False), (12, 10, (5, 5, 34), False),
+    (16, 16, (40, 44, 64), False),
+]
+
+
+@pytest.mark.parametrize("mode", ["plain", "instance", "batch"])
+@pytest.mark.parametrize("case", THIN16_CASES)
+def test_thin16_kernel_fwd_dgrad_and_fused_stats(case, mode):
+    """conv_thin16_k (16x16x32 MFMA, taps packed along K) through the C ABI: forward and data-gradient against fp64 on
+    bf16-exact operands held in pitch-8 buffers whose foreign lanes are NaN; with `mode` != plain the (mean, rstd) that
+    come out of the same launch must equal the statistics of the bf16 output it stored."""
+    ops, L = _ops()
+    from coma_unet_amd._lib import lib
+    cin, cout, dims, per_sample = case
+    B, E, k = 2, 3, 3
+    g = torch.Generator().manual_seed(cin * 37 + cout + dims[2])
+    x = torch.randn((B, cin, *dims), generator=g).bfloat16().double()
+    if per_sample:
+        master = torch.randn((E, cout, cin, k, k, k), generator=g) * 0.2
+        r = torch.rand((B, E), generator=g)
+        wmix = torch.einsum("be,e...->b...", r.double(), master.double()).float().bfloat16().double()
+        bias = torch.randn((B, cout), generator=g)
+    else:
+        master = (torch.randn((cout, cin, k, k, k), generator=g) * 0.2).bfloat16().float()
+        r = None
+        wmix = master.double().unsqueeze(0).expand(B, cout, cin, k, k, k)
+        bias = torch.randn((cout,), generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.cat([F.conv3d(xr[i:i + 1], wmix[i], (bias[i] if per_sample else bias).double(), padding=1) for i in range(B)], 0)
+    gy = torch.randn(yr.shape, generator=g).bfloat16().double()
+    yr.backward(gy)
+
+    def padded(t_ext):
+        v = to_int(t_ext).to("cuda", torch.bfloat16)
+        C = v.shape[-1]
+        if C % 8 == 0:
+            return v
+        buf = torch.full(tuple(v.shape[:4]) + ((C + 7) // 8 * 8,), float("nan"), dtype=torch.bfloat16, device="cuda")
+        buf[..., :C] = v
+        return buf[..., :C]
+
+    xi = padded(x)
+    rg = r.cuda() if per_sample else None
+    wk_f, wk_d = ops.PrepWeights.apply(master.cuda(), rg, False, torch.bfloat16, torch.bfloat16)
+    norm = None
+    if mode != "plain":
+        n = cout
+        norm = (L.NORM_INSTANCE if mode == "instance" else L.NORM_BATCH, 1e-5, None, None, 0.1)
+    y, mean, rstd = ops._conv_fwd(xi, wk_f, bias.cuda(), k, 1, 0, per_sample, 2, None, norm)
+    assert lib.coma_last_kernel().decode().startswith("conv_thin16_k"), lib.coma_last_kernel()
+    assert torch.isfinite(y.float()).all() and rel(to_ext(y), yr) < 5e-3
+    if norm is not None:
+        yf = y.double()
+        red = (1, 2, 3) if mode == "instance" else (0, 1, 2, 3)
+        m_ref = yf.mean(red).reshape(mean.shape)
+        v_ref = yf.var(red, unbiased=False).reshape(mean.shape)
+        assert float((mean.double() - m_ref).abs().max()) < 1e-5 * (1.0 + float(m_ref.abs().max()))
+        assert rel(rstd.double(), (v_ref + 1e-5).rsqrt()) < 1e-5
+    if mode == "plain":
+        dyi = padded(gy)
+        dx, _, _ = ops._conv_bwd(xi, wk_d, dyi, k, 1, 0, per_sample, 2, None, True, False, 0, None)
+        assert cout > 16 or lib.coma_last_kernel().decode().startswith("conv_thin16_k"), lib.coma_last_kernel()
+        assert torch.isfinite(dx.float()).all() and rel(to_ext(dx), xr.grad) < 5e-3
