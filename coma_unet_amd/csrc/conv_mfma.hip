@@ -508,6 +508,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   constexpr int EPB = elem<T>::EPB;
   constexpr bool F32 = EPB == 4;
   static_assert(!F32 || (VEC == 1 && OCC == 1 && RESIDENT == 2), "fp32: vector staging, one block per CU, per-chunk weights");
+  constexpr bool THIN = RESIDENT == 1 && OCC == 2;      // the few-channel variant (one chunk per tile, two blocks per CU)
   constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
   constexpr int CPR = CK / EPB, KS = CPR / 2;        // 16-byte pieces per row, fragment reads per tap and operand
   constexpr int P = CPR == 4 ? 80 : 48;               // LDS row pitch (bytes): 16 rows land on 16 distinct 16-B slots
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
     const bool has_next = nid < id_end;
 
     f32x16_t acc[2];
-    if (!(RESIDENT && OCC == 2)) {   // (thin variant: one chunk, the first MFMA of the tile takes a literal-zero C operand)
+    if (!THIN) {   // (thin variant: one chunk, the first MFMA of the tile takes a literal-zero C operand)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -751,14 +752,30 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
         for (int t = 0; t < 27; ++t) {
           if (t + 1 < 27) rd(t + 1, (t + 1) & 1);
           pref_piece(t);
-          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!(!F32 && KS == 2 && OCC == 1)) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-              acc[i] = mma_piece(wv[t & 1][ks], xv[t & 1][i][ks], (OCC == 2 && t == 0 && ks == 0) ? zero : acc[i], T());
+              acc[i] = mma_piece(wv[t & 1][ks], xv[t & 1][i][ks], (THIN && t == 0 && ks == 0) ? zero : acc[i], T());
             }
+          // one tap = 4 MFMAs (bf16, KS = 2): the next tap's 6 fragment reads and this tap's prefetch piece (address
+          // arithmetic + one buffer load) go BETWEEN them, not in front: an in-order wave otherwise issues ~100 cycles of
+          // LDS / VALU work while the matrix pipe has only the tail of the previous tap to run
+          if constexpr (!F32 && KS == 2 && OCC == 1) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         STAMP(t5);
@@ -825,7 +842,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
           }
         }
       } else
-      if (OCC == 1 && p.st16 && n0 + 32 <= p.N) {
+      if (!THIN && p.st16 && n0 + 32 <= p.N) {
         // Full 32-channel tiles: the two half-waves exchange 4-channel groups (v_permlane32_swap), so that every lane
         // owns 8 CONSECUTIVE channels of its voxel and writes them with one 16-byte store (lanes fh = 0: channels
         // 16 gp + 0..7, fh = 1: 16 gp + 8..15) instead of four 8-byte stores that each cover a quarter of a 64-byte row.
@@ -850,7 +867,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
           const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
           if (valid) *reinterpret_cast<uint4*>(vox + 16 * gp) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
-      } else if (OCC == 2 && p.st16 && n0 + 16 <= p.N && ((p.N - n0) & 15) == 0) {
+      } else if (THIN && p.st16 && n0 + 16 <= p.N && ((p.N - n0) & 15) == 0) {
         // thin variant, 16 (or 32) output channels: the same exchange, one 16-byte store per lane and 16 channels
         const bool valid = gz < p.D && gy < p.H && gx < p.W;
         bf16_t* vox = yb + ((long)(gz * p.H + gy) * p.W + gx) * p.ldy + n0 + 8 * fh;
@@ -892,14 +909,14 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
           // of a call that did not ask for them are not computed at all
           // (thin variant only: on the one-block-per-CU kernel the same branches measured 328-340 -> 402 us on the
           // 32 -> 32 forward, boxes differing: roughly +15-20 %)
-          if (OCC == 2 && n0 + 8 * g4 >= p.N) continue;
+          if (THIN && n0 + 8 * g4 >= p.N) continue;
           bf16_t o[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float a = acc[i][g4 * 4 + q];
-            if (OCC != 2 || has_bias) a += bv[g4][q];
+            if (!THIN || has_bias) a += bv[g4][q];
             o[q] = static_cast<bf16_t>(a);
-            if (OCC != 2 || do_stats) {
+            if (!THIN || do_stats) {
               const float r = static_cast<float>(o[q]);
               st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]);
             }
