@@ -1,7 +1,7 @@
 """MI355X drop-in for the live loss path of the reference ``criterions`` module.
 
 Same class names / call signatures as /root/reference/criterions.py:
-``RoiMSE`` (:124-211, voxel_wise=False), ``GenerativeContrastiveLoss`` (:485-575),
+``RoiMSE`` (:124-211), ``GenerativeContrastiveLoss`` (:485-575),
 ``LabelDifference`` / ``FeatureSimilarity`` / ``RnCLoss`` (:579-644).  The voxel losses are
 fused HIP kernels (one pass: label->weight LUT, squared/absolute difference, per-sample
 reduction; gradient in one more pass).  RnC works on a (B, 512) feature matrix and a (B, 6)
@@ -26,17 +26,42 @@ def _vol_internal(t: torch.Tensor, dtype=None):
 class RoiMSE(nn.Module):
     """loss_b = mean_vox(mask_b) * mean_vox((pred_b - gt_b)^2), mask = ROI weight of each voxel's label."""
 
-    def __init__(self, roi_weights, roi_indices, reduction="mean", scale_factor=360, voxel_wise=False):
+    def __init__(self, roi_weights, roi_indices, reduction="mean", scale_factor=360, voxel_wise=False, template=None):
         super().__init__()
-        if voxel_wise:
-            raise NotImplementedError("voxel_wise=True needs data_util.load_template() (a private template file, "
-                                      "criterions.py:138); no live driver uses it (validation.py:146)")
         self.roi_weights = roi_weights
         self.roi_indices = roi_indices
         self.batch_reduction = reduction
         self.scale_factor = scale_factor
         self.voxel_wise = voxel_wise
         self.voxel_weights = None
+        if voxel_wise:
+            # criterions.py:135-145.  The reference reads its label template from a private file
+            # (data_util.load_template(), absent upstream); here it is the `template` argument (a (D, H, W) label volume).
+            if template is None:
+                try:
+                    import data_util
+                    template = data_util.load_template()
+                except Exception as e:
+                    raise NotImplementedError("RoiMSE(voxel_wise=True) needs the label template: pass template=<(D,H,W) label "
+                                              "volume> (the reference loads it with data_util.load_template(), criterions.py:138)") from e
+            roi_mask = torch.as_tensor(template)
+            w = torch.as_tensor(roi_weights, dtype=torch.float32)
+            voxel_weights = torch.ones(tuple(roi_mask.shape), dtype=torch.float32, device=w.device)
+            roi_mask = roi_mask.to(w.device)
+            for i, idx in enumerate(self.roi_indices):
+                voxel_weights[roi_mask == idx] = w[i]
+            norm_voxel_weights = voxel_weights / torch.norm(voxel_weights)
+            nscaling_factor = 5. / torch.mean(norm_voxel_weights)
+            self.voxel_weights = nscaling_factor * norm_voxel_weights
+
+    def calculate_new_voxel_weights(self, errors, voxel_weights, with_update=False):   # criterions.py:161-168
+        new_weights = voxel_weights * (1 + errors.to(device=self.voxel_weights.device))
+        new_weights = new_weights / torch.norm(new_weights)
+        scaling_factor = torch.mean(voxel_weights) / torch.mean(new_weights)
+        new_weights *= scaling_factor
+        if with_update:
+            self.update_weights(new_weights)
+        return new_weights
 
     def __str__(self):
         return (f"RoiMSE(\n  (roi_indices, roi_weights)={list(zip(self.roi_indices, self.roi_weights))}\n"
@@ -64,8 +89,21 @@ class RoiMSE(nn.Module):
 
     def forward(self, pred, gt, roi):
         dev = pred.device
-        ids, w = self._tables(dev)
         p = _vol_internal(pred)
+        if self.voxel_weights is not None:
+            # criterions.py:189-198: the mask is the (constant) voxel-weight volume, and the per-sample loss is
+            # mean(mask * mean_vox((pred - gt)^2)) = mean(voxel_weights) * MSE_b: the same fused kernel with one label
+            # (every voxel "0") whose weight is that mean (5 by construction, :143-145)
+            key = (dev, tuple(p.shape[:4]))
+            if getattr(self, "_vw_key", None) != key:
+                self._vw = (torch.zeros(1, dtype=torch.int32, device=dev),
+                            self.voxel_weights.float().mean().reshape(1).to(dev).contiguous(),
+                            torch.zeros(tuple(p.shape[:4]) + (1,), dtype=torch.float32, device=dev))
+                self._vw_key = key
+            ids0, w0, zeros = self._vw
+            loss = ops.RoiMSELoss.apply(p, _vol_internal(gt, p.dtype).contiguous(), zeros, ids0, w0)
+            return torch.mean(loss) if self.batch_reduction == "mean" else loss
+        ids, w = self._tables(dev)
         loss = ops.RoiMSELoss.apply(p, _vol_internal(gt, p.dtype).contiguous(),
                                     _vol_internal(roi, torch.float32).contiguous(), ids, w)   # (B, 1)
         if self.batch_reduction == "mean":

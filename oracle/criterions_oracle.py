@@ -21,27 +21,38 @@ import torch.nn as nn
 
 
 class RoiMSE(nn.Module):
-    """criterions.py:124-211, ``voxel_wise=False`` path (the only live one:
-    validation.py:146).  loss_b = mean_vox(mask_b) * mean_vox((pred_b-gt_b)^2)."""
+    """criterions.py:124-211.  ``voxel_wise=False`` is the only live path (validation.py:146):
+    loss_b = mean_vox(mask_b) * mean_vox((pred_b-gt_b)^2); ``voxel_wise=True`` replaces the mask by the constant
+    voxel-weight volume built from a label template (unpinned: the template file is private upstream)."""
 
-    def __init__(self, roi_weights, roi_indices, reduction="mean", scale_factor=360, voxel_wise=False):
+    def __init__(self, roi_weights, roi_indices, reduction="mean", scale_factor=360, voxel_wise=False, template=None):
         super().__init__()
-        assert not voxel_wise, "voxel_wise=True needs a template file the reference does not ship"
+        assert not voxel_wise or template is not None, "voxel_wise=True needs the label template (data_util.load_template() upstream)"
         self.roi_weights = roi_weights
         self.roi_indices = roi_indices
         self.batch_reduction = reduction
         self.scale_factor = scale_factor
         self.voxel_wise = voxel_wise
         self.voxel_weights = None
+        if voxel_wise:   # criterions.py:135-145, with the template handed in instead of data_util.load_template()
+            voxel_weights = torch.ones(tuple(template.shape))
+            roi_mask = torch.as_tensor(template)
+            for i, idx in enumerate(self.roi_indices):
+                voxel_weights[roi_mask == idx] = float(self.roi_weights[i])
+            norm_voxel_weights = voxel_weights / torch.norm(voxel_weights)
+            nscaling_factor = 5. / torch.mean(norm_voxel_weights)
+            self.voxel_weights = nscaling_factor * norm_voxel_weights
 
     def calculate_new_weights(self, errors, with_update=False):  # criterions.py:154-159
         new_weights = self.roi_weights * (1 / 2) * errors.to(device=self.roi_weights.device)
         return self.scale_factor * (new_weights / torch.norm(new_weights))
 
     def forward(self, pred, gt, roi):
-        mask = torch.zeros(roi.size(), device=roi.device, dtype=pred.dtype)
+        mask = (torch.ones if self.voxel_wise else torch.zeros)(roi.size(), device=roi.device, dtype=pred.dtype)   # :182
         for i, idx in enumerate(self.roi_indices):
             mask[roi == idx] = float(self.roi_weights[i])
+        if self.voxel_weights is not None:   # :189-190
+            mask = self.voxel_weights.to(device=pred.device, dtype=pred.dtype).unsqueeze(0).expand_as(pred)
         l = torch.mean(torch.square(pred - gt), dim=(-3, -2, -1))
         loss = torch.zeros(l.size(), device=pred.device, dtype=pred.dtype)
         for b in range(pred.size(0)):

@@ -144,3 +144,22 @@ def test_product_rnc_matches_reference_golden():
         if torch.is_tensor(loss) and loss.requires_grad:
             loss.backward()
             assert rel(feats.grad, g[f"rnc{ci}_grad"]) < 1e-5
+
+
+def test_roimse_voxel_wise_closed_form():
+    """criterions.py:135-145,189-198: with voxel_wise=True the mask is the normalised voxel-weight volume whose mean is 5
+    by construction, so loss_b = 5 * MSE_b whatever the template and the ROI weights are (unpinned: the reference's
+    template file is private; this checks the restatement against the algebra of the reference text)."""
+    from oracle.criterions_oracle import RoiMSE
+    from oracle.coma_oracle import ROI_INDICES
+    g = torch.Generator().manual_seed(5)
+    D = 12
+    template = torch.tensor(ROI_INDICES + [0, 0, 0])[torch.randint(0, len(ROI_INDICES) + 3, (D, D, D), generator=g)]
+    w = torch.rand(len(ROI_INDICES), generator=g) * 300 + 1
+    crit = RoiMSE(w, ROI_INDICES, reduction=None, voxel_wise=True, template=template)
+    assert abs(float(crit.voxel_weights.mean()) - 5.0) < 1e-4
+    pred, gt = torch.randn((3, 1, D, D, D), generator=g).double(), torch.randn((3, 1, D, D, D), generator=g).double()
+    roi = template.double().expand(3, 1, D, D, D)
+    loss = crit(pred, gt, roi)
+    want = 5.0 * ((pred - gt) ** 2).mean(dim=(-3, -2, -1))
+    assert torch.allclose(loss, want, rtol=1e-5)

@@ -613,3 +613,37 @@ def test_thin16_kernel_fwd_dgrad_and_fused_stats(case, mode):
         dx, _, _ = ops._conv_bwd(xi, wk_d, dyi, k, 1, 0, per_sample, 2, None, True, False, 0, None)
         assert cout > 16 or lib.coma_last_kernel().decode().startswith("conv_thin16_k"), lib.coma_last_kernel()
         assert torch.isfinite(dx.float()).all() and rel(to_ext(dx), xr.grad) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_roimse_voxel_wise_matches_oracle(dtype):
+    """RoiMSE(voxel_wise=True) (criterions.py:135-145,189-198) with the template passed in: per-sample loss and its
+    gradient against the CPU restatement (unpinned: the reference's template file is private)."""
+    _ops()
+    from coma_unet_amd.criterions import RoiMSE
+    from coma_unet_amd.roi_tables import ROI_INDICES
+    from oracle.criterions_oracle import RoiMSE as ORoiMSE
+    g = torch.Generator().manual_seed(11)
+    D, H, W = 10, 12, 33
+    template = torch.tensor(list(ROI_INDICES) + [0, 0, 0])[torch.randint(0, len(ROI_INDICES) + 3, (D, H, W), generator=g)]
+    w = torch.rand(len(ROI_INDICES), generator=g) * 300 + 1
+    pred = torch.randn((3, 1, D, H, W), generator=g).to(dtype)
+    gt = torch.randn((3, 1, D, H, W), generator=g).to(dtype)
+    roi = template.float().expand(3, 1, D, H, W).contiguous()
+    oc = ORoiMSE(w, ROI_INDICES, reduction=None, voxel_wise=True, template=template)
+    pr = pred.double().requires_grad_(True)
+    lo = oc(pr, gt.double(), roi.double())
+    go = torch.rand(lo.shape, generator=g).double()
+    (lo * go).sum().backward()
+    crit = RoiMSE(w, ROI_INDICES, reduction=None, voxel_wise=True, template=template)
+    assert abs(float(crit.voxel_weights.mean()) - 5.0) < 1e-4
+    pg = pred.cuda().requires_grad_(True)
+    lg = crit(pg, gt.cuda(), roi.cuda())
+    assert tuple(lg.shape) == tuple(lo.shape)
+    assert rel(lg.double().cpu(), lo) < 1e-5
+    (lg * go.float().cuda()).sum().backward()
+    assert rel(pg.grad.double().cpu(), pr.grad) < (1e-5 if dtype == torch.float32 else 6e-3)
+    crit.batch_reduction = "mean"
+    assert abs(float(crit(pg, gt.cuda(), roi.cuda())) - float(lo.mean())) < 1e-5 * abs(float(lo.mean()))
+    with pytest.raises(NotImplementedError):
+        RoiMSE(w, ROI_INDICES, voxel_wise=True)        # no template and no data_util module: the reference's private file
