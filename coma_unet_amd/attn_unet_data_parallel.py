@@ -317,6 +317,7 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         if covariate is not None:     # one cast for every conditional layer (each routing reads fp32 covariates)
             covariate = covariate.to(device=x.device, dtype=torch.float32).contiguous()
         xi = _padded_input(x, self.cfg.compute_dtype)
+        ops.SidePrep.begin(x.device)      # weight preparation runs beside the convolutions from here on
         cfgs = (self.cfg, self.cfg_heads) if self.training else ()
         for c in cfgs:
             c.begin_forward()

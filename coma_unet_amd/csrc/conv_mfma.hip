@@ -2133,6 +2133,7 @@ struct Wgrad2P {
   int N, C, D, H, W;
   int ntx, nty, ntz, tiles_total, tiles_per_block, cblocks;
   int vec_n, vec_c;
+  int lgd, lgg;                 // log2 of the 8-channel chunks per staged dy / x row that are dealt to threads (1, 2 or 4)
   float* dwk; long wsb;
   int nrep; long rep_stride;    // small outputs: blocks merge into one of nrep replicas (summed afterwards)
 };
@@ -2208,8 +2209,13 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
   const bf16_t* dyb = p.dyp + (long)b * p.sbn + n0;
   const bf16_t* xb = p.xp + (long)b * p.sbc + c0;
   const int chn = p.N - n0, chc = p.C - c0;      // valid channels of this block's slices
-  const int ch = tid & 3;                        // every piece of this thread has the same 8-channel chunk
-  const bool dlive = ch * 8 < chn, glive = ch * 8 < chc;
+  // Staging: a 16-byte piece = 8 channels of one row.  Rows keep their 64-byte LDS slots, but only the 1, 2 or 4 chunks
+  // a thin operand really has are dealt to the threads (p.lgd / p.lgg = log2 of that count): with the fixed 4-chunks-
+  // per-row deal an 8-channel operand kept 3 of 4 lanes idle through 13 + 4 quarter-filled load instructions per tile.
+  // Every piece of a thread still has the same 8-channel chunk (256 is a multiple of the chunk count).
+  const int lgd = p.lgd, lgg = p.lgg;
+  const int chd = tid & ((1 << lgd) - 1), chg = tid & ((1 << lgg) - 1);
+  const bool dlive = chd * 8 < chn, glive = chg * 8 < chc;
 
   // zero the whole LDS image once: padding channels / never-staged pieces stay zero
   for (int i = tid; i < NDP + NGP; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
@@ -2249,42 +2255,47 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
     if (dlive) {
 #pragma unroll
       for (int it = 0; it < DIT; ++it) {
-        const int row = (tid >> 2) + 64 * it;
+        const int row = (tid + 256 * it) >> lgd;
         const int vx = row & 31, vy = (row >> 5) & 3, vz = row >> 7;
         const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
         dv[it] = make_uint4(0, 0, 0, 0);
-        if (gz < p.D && gy < p.H && gx < p.W) {
-          const bf16_t* src = dyb + (unsigned)(((gz * p.H + gy) * p.W + gx) * p.ldn + ch * 8);   // < 2^31 elements (checked)
-          dv[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8_raw(src, chn - ch * 8, p.vec_n);
+        if (row < TM && gz < p.D && gy < p.H && gx < p.W) {
+          const bf16_t* src = dyb + (unsigned)(((gz * p.H + gy) * p.W + gx) * p.ldn + chd * 8);   // < 2^31 elements (checked)
+          dv[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8_raw(src, chn - chd * 8, p.vec_n);
         }
       }
     }
     if (glive) {
 #pragma unroll
       for (int it = 0; it < GIT; ++it) {
-        const int row = (tid >> 2) + 64 * it;
+        const int row = (tid + 256 * it) >> lgg;
         const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
         const int gz = z0 - PADK + hz, gy = y0 - PADK + hy, gx = x0 - PADK + hx;
         gv[it] = make_uint4(0, 0, 0, 0);
         if (row < HV && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
-          const bf16_t* src = xb + (unsigned)(((gz * p.H + gy) * p.W + gx) * p.ldc + ch * 8);
-          gv[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8_raw(src, chc - ch * 8, p.vec_c);
+          const bf16_t* src = xb + (unsigned)(((gz * p.H + gy) * p.W + gx) * p.ldc + chg * 8);
+          gv[it] = VEC ? *reinterpret_cast<const uint4*>(src) : load8_raw(src, chc - chg * 8, p.vec_c);
         }
       }
     }
   };
   // (every piece of a thread has the same channel chunk: one mask per operand, applied when the piece goes to LDS)
-  const uint4 dmask = mask8(VEC ? 8 : chn - ch * 8), gmask = mask8(VEC ? 8 : chc - ch * 8);
+  const uint4 dmask = mask8(VEC ? 8 : chn - chd * 8), gmask = mask8(VEC ? 8 : chc - chg * 8);
   auto and4 = [](uint4 v, uint4 m) { v.x &= m.x; v.y &= m.y; v.z &= m.z; v.w &= m.w; return v; };
   auto store_tile = [&]() {
     if (dlive) {
 #pragma unroll
-      for (int it = 0; it < DIT; ++it) reinterpret_cast<uint4*>(Dt)[tid + 256 * it] = VEC ? dv[it] : and4(dv[it], dmask);
+      for (int it = 0; it < DIT; ++it) {
+        const int row = (tid + 256 * it) >> lgd;
+        if (row < TM) reinterpret_cast<uint4*>(Dt)[row * 4 + chd] = VEC ? dv[it] : and4(dv[it], dmask);
+      }
     }
     if (glive) {
 #pragma unroll
-      for (int it = 0; it < GIT; ++it)
-        if (tid + 256 * it < NGP) reinterpret_cast<uint4*>(Gt)[tid + 256 * it] = VEC ? gv[it] : and4(gv[it], gmask);
+      for (int it = 0; it < GIT; ++it) {
+        const int row = (tid + 256 * it) >> lgg;
+        if (row < HV) reinterpret_cast<uint4*>(Gt)[row * 4 + chg] = VEC ? gv[it] : and4(gv[it], gmask);
+      }
     }
   };
 
@@ -2354,6 +2365,10 @@ static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const
   p.ntx = (p.W + 31) / 32; p.nty = (p.H + 3) / 4; p.ntz = (p.D + 1) / 2;
   p.tiles_total = p.ntx * p.nty * ((p.ntz + 7) / 8) * 8;
   p.cblocks = (p.C + 31) / 32;
+  {   // live 8-channel chunks per staged row, rounded up to 1 / 2 / 4 (blocks of a wide operand always see 4)
+    const int nd = p.N > 32 ? 4 : (p.N + 7) / 8, ng = p.C > 32 ? 4 : (p.C + 7) / 8;
+    p.lgd = nd <= 1 ? 0 : nd <= 2 ? 1 : 2; p.lgg = ng <= 1 ? 0 : ng <= 2 ? 1 : 2;
+  }
   const int pairs = ((p.N + 31) / 32) * p.cblocks;
   p.vec_n = dy->ld % 8 == 0 && dy->sb % 8 == 0 && (((uintptr_t)dy->data) & 15) == 0;
   p.vec_c = x->ld % 8 == 0 && x->sb % 8 == 0 && (((uintptr_t)x->data) & 15) == 0;

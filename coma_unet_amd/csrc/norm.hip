@@ -261,22 +261,32 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
   }
 }
 
-// stage 1: one wave per (g,c) reduces the chunk partials -> tot[(g*C+c)*3 .. +3] (fp64) and the fp32 means
+// stage 1: one wave per channel reduces the chunk partials of each of its groups -> tot[(g*C+c)*3 .. +3] (fp64), the fp32
+// means, and dgamma / dbeta[c] = sum over the groups (in group order: the same sum the separate finaliser made)
 __global__ __launch_bounds__(256) void norm_bwd_reduce_k(const double* partial, int nchunks, int G, int C, int64_t R,
-                                                         double* tot, float* sums) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                         double* tot, float* sums, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (i >= G * C) return;
-  double a = 0.0, b = 0.0, s = 0.0;
-  for (int k = lane; k < nchunks; k += 64) {
-    const double* v = partial + ((int64_t)k * G * C + i) * 3;
-    a += v[0]; b += v[1]; s += v[2];
+  if (c >= C) return;
+  double dg = 0.0, db = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const int i = g * C + c;
+    double a = 0.0, b = 0.0, s = 0.0;
+    for (int k = lane; k < nchunks; k += 64) {
+      const double* v = partial + ((int64_t)k * G * C + i) * 3;
+      a += v[0]; b += v[1]; s += v[2];
+    }
+    a = wave_sum(a); b = wave_sum(b); s = wave_sum(s);
+    if (lane == 0) {
+      tot[i * 3] = a; tot[i * 3 + 1] = b; tot[i * 3 + 2] = s;
+      sums[i * 2] = (float)(a / (double)R);
+      sums[i * 2 + 1] = (float)(b / (double)R);
+    }
+    db += a; dg += b;
   }
-  a = wave_sum(a); b = wave_sum(b); s = wave_sum(s);
   if (lane == 0) {
-    tot[i * 3] = a; tot[i * 3 + 1] = b; tot[i * 3 + 2] = s;
-    sums[i * 2] = (float)(a / (double)R);
-    sums[i * 2 + 1] = (float)(b / (double)R);
+    if (dgamma) dgamma[c] = (float)dg;
+    if (dbeta) dbeta[c] = (float)db;
   }
 }
 // stage 2: dgamma/dbeta[c] = sum over groups, dslope = sum over everything (<= 1024 numbers)
@@ -494,11 +504,11 @@ extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, in
   else { if (pvec == 8) L(bf16_t, 8); else if (pvec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
 #undef L
   COMA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_bwd_reduce_k, dim3((rp.G * rp.C + 3) / 4), dim3(256), 0, s, partial, rp.nchunks, rp.G, rp.C,
-                     rp.R, tot, sums);
+  hipLaunchKernelGGL(norm_bwd_reduce_k, dim3((rp.C + 3) / 4), dim3(256), 0, s, partial, rp.nchunks, rp.G, rp.C,
+                     rp.R, tot, sums, dgamma, dbeta);
   COMA_LAUNCH_CHECK();
-  if (dgamma || dbeta || dslope) {
-    hipLaunchKernelGGL(norm_bwd_finalize_k, dim3(1), dim3(256), 0, s, tot, rp.G, rp.C, dgamma, dbeta, dslope);
+  if (dslope) {          // the PReLU slope is one number summed over every (group, channel): its own small launch
+    hipLaunchKernelGGL(norm_bwd_finalize_k, dim3(1), dim3(256), 0, s, tot, rp.G, rp.C, (float*)nullptr, (float*)nullptr, dslope);
     COMA_LAUNCH_CHECK();
   }
   int avec = vec;

@@ -193,7 +193,16 @@ def conv_cond(cfg, x, cc: CondConv3d, covariate, out=None, norm=None):
     if cov.dtype != torch.float32 or cov.device != x.device or not cov.is_contiguous():
         cov = cov.to(device=x.device, dtype=torch.float32).contiguous()   # the model casts once per forward
     assert cov.shape[1] == cc.num_covars, (cov.shape, cc.num_covars)
-    r, bias = ops.Routing.apply(cov, cc.routing.weight, cc.routing.bias, cc.bias)    # (B, E), (B, Cout)
+    if ops.SidePrep._on:     # routing reads covariates and parameters only: on the weight-preparation stream (ops.SidePrep)
+        with torch.cuda.stream(ops.SidePrep.stream(x.device)):
+            r, bias = ops.Routing.apply(cov, cc.routing.weight, cc.routing.bias, cc.bias)
+        # allocated from the side stream's pool, read by kernels of this stream (bias: the convolution's epilogue; r: the
+        # backward scatter): without this the allocator hands the block to the NEXT layer's routing as soon as python drops it
+        main = torch.cuda.current_stream(x.device)
+        r.record_stream(main)
+        bias.record_stream(main)
+    else:
+        r, bias = ops.Routing.apply(cov, cc.routing.weight, cc.routing.bias, cc.bias)    # (B, E), (B, Cout)
     a_f, a_d = ops.pick_algo(x.shape, x.dtype, cc.out_channels, cc.kernel_size, cc.stride, cc.is_transposed, True,
                              x.device, cfg.conv_algo)
     need_dx = x.requires_grad

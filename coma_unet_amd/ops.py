@@ -7,6 +7,8 @@ library on the current stream; none of them has a CPU or PyTorch fallback.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -119,6 +121,8 @@ class GradSink:
     @classmethod
     def begin_step(cls):
         cls.written.clear()
+        SidePrep.join()
+        SidePrep._live = 0
 
     @classmethod
     def slot(cls, p):
@@ -134,11 +138,86 @@ class GradSink:
         return p.grad
 
 
+class SidePrep:
+    """Weight preparation off the critical path.  Routing, the expert mix / re-layout of the masters and (backward) the
+    scatter of the kernel-layout weight gradient to the experts depend on parameters and covariates only, never on an
+    activation -- but in one stream they sit between the convolutions (~110 launches of 4-20 us forward, ~50 backward, plus
+    ~1.3 ms of bandwidth-bound mixes on the deep layers).  They run on a second HIP stream here: forked at the start of a
+    model forward, every convolution waits for the event of ITS weights only, the backward scatters are joined before the
+    optimizer.  Under hipGraph capture the stream becomes a parallel branch of the graph.
+
+    Prepared weights live in persistent per-layer buffers (they are read by the convolution on the main stream after
+    the preparing call has returned: an allocator block could be handed out again on the side stream too early).  A second
+    forward before the backward of the first (or a layer used twice in one forward) falls back to the one-stream path."""
+    # OFF by default: measured on the 128^3 step (hipGraph replay) it is SLOWER, 22.68 ms one stream -> 23.31 ms (forward
+    # and backward on the side stream) / 23.78 ms (forward only): the ~200 cross-stream dependencies of the graph cost more
+    # than the ~1 ms of small launches and bandwidth-bound mixes they take off the main chain.  COMA_SIDE_PREP=1 enables it.
+    enabled = os.environ.get("COMA_SIDE_PREP", "0") not in ("0", "")
+    backward = os.environ.get("COMA_SIDE_PREP", "0") != "f"      # ("f": forward preparation only)
+    _streams, _bufs, _used = {}, {}, set()
+    _live = 0          # ConvLayer nodes whose backward still needs the persistent dgrad weights
+    _on = False
+
+    @classmethod
+    def stream(cls, dev):
+        key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=key)
+        return cls._streams[key]
+
+    @classmethod
+    def begin(cls, dev):
+        """Start of a model forward."""
+        cls._on = False
+        if not cls.enabled or GradSink.listener is not None or cls._live > 0 or torch.device(dev).type != "cuda":
+            return
+        cls.stream(dev).wait_stream(torch.cuda.current_stream(dev))
+        cls._used.clear()
+        cls._on = True
+
+    @classmethod
+    def fence(cls, dev):
+        """The current stream waits for everything queued on the side stream so far."""
+        ev = torch.cuda.Event()
+        ev.record(cls.stream(dev))
+        torch.cuda.current_stream(dev).wait_event(ev)
+        if os.environ.get("COMA_SIDE_SYNC") == "1":      # (debugging aid: no overlap at all)
+            torch.cuda.synchronize(dev)
+
+    @classmethod
+    def follow(cls, dev):
+        """The side stream waits for everything queued on the current stream so far."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        cls.stream(dev).wait_event(ev)
+
+    @classmethod
+    def join(cls):
+        for key, st in cls._streams.items():
+            torch.cuda.current_stream(key).wait_stream(st)
+        cls._on = False
+
+    @classmethod
+    def buffers(cls, master, shape_f, fwd_dtype, shape_d, dgrad_dtype):
+        """Persistent (wk_f, wk_d) of this layer, or None when it was already prepared in this forward."""
+        if id(master) in cls._used:
+            return None
+        cls._used.add(id(master))
+        key = (id(master), tuple(shape_f), fwd_dtype, dgrad_dtype)
+        ent = cls._bufs.get(key)
+        if ent is None or ent[0] is not master:
+            dev = master.device
+            ent = (master, _new(shape_f, fwd_dtype, dev), _new(shape_d, dgrad_dtype, dev) if dgrad_dtype is not None else None)
+            cls._bufs[key] = ent
+        return ent[1], ent[2]
+
+
 # --------------------------------------------------------------------------------------
 # weights: CondConv expert mixing + kernel-layout cast
 # --------------------------------------------------------------------------------------
-def _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype):
-    """-> wk_f [Bw, taps, Cout, Cin], wk_d [Bw, taps, Cin, Cout] or None, r (fp32, contiguous) or None, meta."""
+def _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype, bufs=None):
+    """-> wk_f [Bw, taps, Cout, Cin], wk_d [Bw, taps, Cin, Cout] or None, r (fp32, contiguous) or None, meta.
+    bufs: "persistent" takes the layer's SidePrep buffers when they are free (returns side=True in that case)."""
     has_e = r is not None
     m = master if has_e else master.unsqueeze(0)
     assert m.is_contiguous() and m.dtype == torch.float32
@@ -153,8 +232,11 @@ def _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype):
     Bw = r.shape[0] if has_e else 1
     rr = r.contiguous().float() if has_e else None
     dev = master.device
-    wk_f = _new((Bw, taps, cout, cin), fwd_dtype, dev)
-    wk_d = _new((Bw, taps, cin, cout), dgrad_dtype, dev) if dgrad_dtype is not None else None
+    if bufs is not None:
+        wk_f, wk_d = bufs
+    else:
+        wk_f = _new((Bw, taps, cout, cin), fwd_dtype, dev)
+        wk_d = _new((Bw, taps, cin, cout), dgrad_dtype, dev) if dgrad_dtype is not None else None
     if taps == 27:
         # one pass over the experts writes both layouts: [tap][A][B] and [tap][B][A] of master [E][A][B][27]
         ab, ba = (wk_d, wk_f) if transposed else (wk_f, wk_d)
@@ -379,9 +461,28 @@ class ConvLayer(Function):
         ctx.set_materialize_grads(False)
         per_sample = r is not None
         form = 1 if transposed else 0
-        wk_f, wk_d, rr, pmeta = _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype)
+        side = False
+        if SidePrep._on:
+            E_ = master.shape[0] if per_sample else 1
+            A_, B_ = master.shape[-5], master.shape[-4]
+            taps_ = ksize ** 3
+            cout_, cin_ = (B_, A_) if transposed else (A_, B_)
+            Bw_ = r.shape[0] if per_sample else 1
+            bufs = SidePrep.buffers(master, (Bw_, taps_, cout_, cin_), fwd_dtype, (Bw_, taps_, cin_, cout_), dgrad_dtype)
+            if bufs is not None:
+                with torch.cuda.stream(SidePrep.stream(x.device)):
+                    wk_f, wk_d, rr, pmeta = _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype, bufs)
+                SidePrep.fence(x.device)
+                side = True
+        if not side:
+            if SidePrep._on:
+                SidePrep.fence(x.device)      # (routing / bias mix of this layer were queued on the side stream)
+            wk_f, wk_d, rr, pmeta = _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype)
         y, mean, rstd = _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm)
         ctx.save_for_backward(x, wk_d, master, rr)
+        ctx.side = side
+        if side and any(ctx.needs_input_grad):
+            SidePrep._live += 1
         ctx.p_master, ctx.p_bias = master, (bias if not per_sample else None)
         # per-sample biases survive a BATCH norm (only their batch mean is removed); an instance norm removes them
         removed = norm is not None and (not per_sample or norm[0] == L.NORM_INSTANCE)
@@ -402,8 +503,20 @@ class ConvLayer(Function):
         dx, dwk, dbias = _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, ctx.needs_input_grad[0],
                                    need_dw, bias_mode, ctx.p_bias)
         dmaster = dr = None
+        if ctx.side:
+            SidePrep._live = max(0, SidePrep._live - 1)
         if need_dw:
-            dmaster, dr = _prep_bwd(dwk, master, rr, pmeta, ctx.p_master)
+            # the scatter to the experts runs on the side stream when its result is written through to the flat gradient
+            # buffer (nothing on this stream reads it before the optimizer) and the routing node -- the only consumer of
+            # dr -- itself lives on the side stream
+            sunk = getattr(ctx.p_master, "_coma_sink", False) and ctx.p_master.grad is not None and id(ctx.p_master) not in GradSink.written
+            if ctx.side and SidePrep.enabled and SidePrep.backward and GradSink.listener is None and sunk:
+                SidePrep.follow(x.device)
+                dwk.record_stream(SidePrep.stream(x.device))
+                with torch.cuda.stream(SidePrep.stream(x.device)):
+                    dmaster, dr = _prep_bwd(dwk, master, rr, pmeta, ctx.p_master)
+            else:
+                dmaster, dr = _prep_bwd(dwk, master, rr, pmeta, ctx.p_master)
         return (dx, dmaster, dr, dbias) + (None,) * 9
 
 

@@ -96,6 +96,7 @@ class FusedAdamW(torch.optim.Optimizer):
         of it -- the data-parallel step with a reduce-scattered gradient updates this rank's slices and all-gathers the
         parameters afterwards (data_parallel.StreamedGradExchange); the moments of the other slices are never touched here
         (they live, up to date, on the ranks that own them)."""
+        ops.SidePrep.join()       # the side stream's expert-gradient scatters land in the flat gradient buffer
         g = self.param_groups[0]
         lr, (b1, b2), eps, wd = float(g["lr"]), g["betas"], g["eps"], g["weight_decay"]
         if not self.built:

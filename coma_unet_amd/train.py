@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
 from .optim import FusedAdamW
 from .data_parallel import GradReducer, StreamedGradExchange
 
@@ -51,6 +52,7 @@ def train_step(model, criterion, optimizer, batch, reducer: GradReducer = None, 
         reducer.reset()
     losses, outs = forward_loss(model, criterion, batch, global_rnc)
     losses[0].backward()                                                    # :884
+    ops.SidePrep.join()          # expert-gradient scatters of the weight-preparation stream (ops.SidePrep)
     stepped = False
     if reducer is not None:
         stepped = bool(reducer.finish())       # (a sharded exchange also takes the optimizer step, on its shard)
@@ -110,6 +112,7 @@ class GraphedTrainStep:
                 optimizer.zero_grad()
                 self.losses, self.outputs = forward_loss(model, criterion, self.batch)
                 self.losses[0].backward()
+                ops.SidePrep.join()
         if reducer is None or self.in_graph:
             # capture executes nothing: undo the host-side step count train_step's optimizer.step() just added
             optimizer._flat_step -= 1

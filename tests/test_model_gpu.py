@@ -367,6 +367,52 @@ def test_write_through_gradients_equal_autograd_accumulation():
     assert nbt[0] == nbt[1] and any(v == 6 for v in nbt[0].values()) and any(v == 3 for v in nbt[0].values())
 
 
+def test_side_stream_weight_preparation_equals_one_stream():
+    """ops.SidePrep: routing, expert mix / re-layout and the expert-gradient scatter on a second HIP stream (eager, and as
+    a parallel branch of the captured graph) must give the gradients and parameters of the one-stream order -- compared
+    on the deterministic direct kernels (conv_algo=1), where any missing stream dependency shows as a mismatch."""
+    import coma_unet_amd as cu
+    from coma_unet_amd import ops
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, make_optimizer, GraphedTrainStep
+    S = (32, 32, 32)
+    b = make_batch(2, S, seed=33)
+    res = {}
+    was = ops.SidePrep.enabled
+    try:
+        for mode in ("one-stream", "side", "side-graph"):
+            ops.SidePrep.enabled = mode != "one-stream"
+            torch.manual_seed(9)
+            gm = cu.build_model(volume_shape=S, static_prompts=True, conv_algo=1).cuda()
+            gm.set_save_attn(None)
+            gm.train(True)
+            gb = _gpu_batch(b)
+            gb["roi_pred_dicts"] = gm._priors(b["roi_pred_dicts"], 2, torch.device("cuda"))
+            opt = make_optimizer(gm, 1e-3)
+            crit = cu.build_reference_criterion()
+            losses = []
+            if mode == "side-graph":
+                step = GraphedTrainStep(gm, crit, opt, gb, warmup=2)        # 2 eager warm-up steps, then replays
+                for _ in range(2):
+                    losses.append(float(step()[0][0]))
+            else:
+                for _ in range(4):
+                    losses.append(float(train_step(gm, crit, opt, gb)[0][0]))
+            torch.cuda.synchronize()
+            if mode != "one-stream":
+                assert len(ops.SidePrep._bufs) > 40
+            res[mode] = (losses, opt.flat_g.clone(), opt.flat_p.clone())
+    finally:
+        ops.SidePrep.enabled = was
+    ref_l, ref_g, ref_p = res["one-stream"]
+    for mode in ("side", "side-graph"):
+        l, g, p_ = res[mode]
+        print(mode, l, "vs", ref_l)
+        for a, r in zip(l[-2:], ref_l[-2:]):
+            assert abs(a - r) <= 2e-4 * abs(r), (mode, l, ref_l)       # (loss / norm reductions use fp32 atomics)
+        assert rel(g, ref_g) < 2e-3 and rel(p_, ref_p) < 1e-5, (mode, rel(g, ref_g), rel(p_, ref_p))
+
+
 def test_checkpoint_roundtrip_and_plateau_scheduler(tmp_path):
     """ReduceLROnPlateau drives FusedAdamW (eager and graph-replayed: a learning-rate change re-captures),
     and a checkpoint in the reference's format (attn_unet_data_parallel.py:943-955) restores model, moments, step count
