@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from . import _lib as L
 from . import ops
 from .layers import (Config, Convolution, MonaiConvBlock, CondConvolution, CondConvBlock, norm_act, conv_plain,
-                     conv_then_bn)
+                     conv_then_bn, reset_cov_cache, cov_rows)
 from .ops import Out
 from .roi_tables import ROI_INDICES, ROI_NAMES, ROI_INDEX_TO_NAME
 from .metrics import RoiCorrMetric, calc_roi_metrics          # noqa: F401  (:36-96, :1361-1397 of the reference module)
@@ -193,6 +193,7 @@ class ObservableAttentionUnet(nn.Module):
 
     def forward(self, x, covariate=None):
         xi = _padded_input(x, self.cfg.compute_dtype)
+        reset_cov_cache()
         y, enc, dec = self._unet(xi, covariate)
         return to_external(y), [to_external(e) for e in enc], [to_external(d) for d in dec]
 
@@ -317,7 +318,10 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         if covariate is not None:     # one cast for every conditional layer (each routing reads fp32 covariates)
             covariate = covariate.to(device=x.device, dtype=torch.float32).contiguous()
         xi = _padded_input(x, self.cfg.compute_dtype)
-        ops.SidePrep.begin(x.device)      # weight preparation runs beside the convolutions from here on
+        reset_cov_cache()
+        if covariate is not None and covariate.dim() == 3 and covariate.shape[2] > 5:
+            cov_rows(covariate[:, :, :5], x.shape[0], x.device)      # the 5-covariate layers' rows: one copy, made before the fork
+        ops.SidePrep.begin(x.device)      # (opt-in) weight preparation runs beside the convolutions from here on
         cfgs = (self.cfg, self.cfg_heads) if self.training else ()
         for c in cfgs:
             c.begin_forward()

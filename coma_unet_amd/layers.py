@@ -187,11 +187,31 @@ class CondConv3d(nn.Module):
         nn.init.uniform_(self.bias, -1.0 / fan_in ** 0.5, 1.0 / fan_in ** 0.5)
 
 
+_COV_ROWS = {}
+
+
+def reset_cov_cache():
+    """Start of a model forward: the contiguous covariate rows below are per forward (input buffers are updated in place)."""
+    _COV_ROWS.clear()
+
+
+def cov_rows(covariate, B, device):
+    """(B, n) fp32 contiguous rows of a covariate tensor or of a slice of it (the U-Net hands `covariate[:, :, :5]` to its
+    5-covariate layers: one copy per forward instead of one per layer)."""
+    cov = covariate.reshape(B, -1)
+    if cov.dtype == torch.float32 and cov.device == device and cov.is_contiguous():
+        return cov
+    key = (covariate.data_ptr(), tuple(covariate.shape), tuple(covariate.stride()), covariate.dtype)
+    c = _COV_ROWS.get(key)
+    if c is None:
+        c = cov.to(device=device, dtype=torch.float32).contiguous()
+        _COV_ROWS[key] = c
+    return c
+
+
 def conv_cond(cfg, x, cc: CondConv3d, covariate, out=None, norm=None):
     B = x.shape[0]
-    cov = covariate.reshape(B, -1)
-    if cov.dtype != torch.float32 or cov.device != x.device or not cov.is_contiguous():
-        cov = cov.to(device=x.device, dtype=torch.float32).contiguous()   # the model casts once per forward
+    cov = cov_rows(covariate, B, x.device)
     assert cov.shape[1] == cc.num_covars, (cov.shape, cc.num_covars)
     if ops.SidePrep._on:     # routing reads covariates and parameters only: on the weight-preparation stream (ops.SidePrep)
         with torch.cuda.stream(ops.SidePrep.stream(x.device)):

@@ -207,7 +207,10 @@ class SidePrep:
         ent = cls._bufs.get(key)
         if ent is None or ent[0] is not master:
             dev = master.device
-            ent = (master, _new(shape_f, fwd_dtype, dev), _new(shape_d, dgrad_dtype, dev) if dgrad_dtype is not None else None)
+            # from the SIDE stream's pool: a block of this stream's pool may still be read by a queued kernel of its previous
+            # owner, and the side stream (which runs ahead) would overwrite it without waiting
+            with torch.cuda.stream(cls.stream(dev)):
+                ent = (master, _new(shape_f, fwd_dtype, dev), _new(shape_d, dgrad_dtype, dev) if dgrad_dtype is not None else None)
             cls._bufs[key] = ent
         return ent[1], ent[2]
 
