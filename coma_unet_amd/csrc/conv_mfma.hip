@@ -2213,7 +2213,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_wgrad2_k(Wgrad2P p) {
   // a thin operand really has are dealt to the threads (p.lgd / p.lgg = log2 of that count): with the fixed 4-chunks-
   // per-row deal an 8-channel operand kept 3 of 4 lanes idle through 13 + 4 quarter-filled load instructions per tile.
   // Every piece of a thread still has the same 8-channel chunk (256 is a multiple of the chunk count).
-  const int lgd = p.lgd, lgg = p.lgg;
+  // (PK == 1, the >= 32-channel layers: the compile-time 4-chunk deal -- with run-time shifts the compiler stopped hoisting
+  //  the per-piece row arithmetic out of the tile loop and the 64 -> 32 weight gradient went from 223 to 355 us)
+  const int lgd = PK == 1 ? 2 : p.lgd, lgg = PK == 1 ? 2 : p.lgg;
   const int chd = tid & ((1 << lgd) - 1), chg = tid & ((1 << lgg) - 1);
   const bool dlive = chd * 8 < chn, glive = chg * 8 < chc;
 
