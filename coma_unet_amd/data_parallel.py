@@ -155,6 +155,27 @@ class GradReducer:
             if id(p) not in opt._flat_ids and p.grad is not None:
                 dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
 
+    def reduce_flat_and_step(self):
+        """reduce_flat + optimizer.step(), pipelined: every bucket's all-reduce is queued up front (they run one after the
+        other on the process group's stream) and each bucket's slice of the AdamW step is launched as soon as ITS all-reduce
+        has finished -- the optimizer's 0.9 ms run under the remaining buckets' exchange instead of after it."""
+        opt = self.opt
+        if self.world == 1:
+            opt.step()
+            return
+        assert opt.built, "reduce_flat_and_step needs the flat gradient layout (run two eager steps first)"
+        n = opt.flat_g.numel()
+        spans = [(s, min(self.bucket_elems, n - s)) for s in range(0, n, self.bucket_elems)]
+        works = [dist.all_reduce(opt.flat_g[s:s + k], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, k in spans]
+        loose = [p for p in opt.param_groups[0]["params"] if id(p) not in opt._flat_ids and p.grad is not None]
+        lworks = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for p in loose]
+        for i, ((s, k), w) in enumerate(zip(spans, works)):
+            w.wait()
+            opt.step_shards([(s, k)], advance=i == 0, loose=False)
+        for w in lworks:
+            w.wait()
+        opt.step_shards([], advance=False, loose=True)
+
     def remove_hooks(self):
         for h in self._hooks:
             h.remove()

@@ -91,22 +91,27 @@ class FusedAdamW(torch.optim.Optimizer):
         self.step_shards(None)
 
     @torch.no_grad()
-    def step_shards(self, shards):
+    def step_shards(self, shards, advance=True, loose=True):
         """One AdamW step.  shards=None: the whole flat buffer (one launch).  shards=[(offset, length)]: only those slices
         of it -- the data-parallel step with a reduce-scattered gradient updates this rank's slices and all-gathers the
         parameters afterwards (data_parallel.StreamedGradExchange); the moments of the other slices are never touched here
-        (they live, up to date, on the ranks that own them)."""
+        (they live, up to date, on the ranks that own them).  A step may also be taken slice by slice as the slices'
+        gradients arrive (GradReducer.reduce_flat_and_step): advance=True on the first call only (the step count moves
+        once), loose=True on one call only (parameters outside the flat buffer)."""
         ops.SidePrep.join()       # the side stream's expert-gradient scatters land in the flat gradient buffer
         g = self.param_groups[0]
         lr, (b1, b2), eps, wd = float(g["lr"]), g["betas"], g["eps"], g["weight_decay"]
         if not self.built:
             self._build()
-        self._flat_step += 1
-        self._step_dev += 1            # device-side copy: a captured step keeps counting under graph replay
+        if advance:
+            self._flat_step += 1
+            self._step_dev += 1            # device-side copy: a captured step keeps counting under graph replay
         for off, k in ([(0, self.flat_p.numel())] if shards is None else shards):
             if k > 0:
                 ops.adamw_(self.flat_p[off:off + k], self.flat_g[off:off + k], self.flat_m[off:off + k], self.flat_v[off:off + k],
                            lr, b1, b2, eps, wd, self._flat_step, self._step_dev)
+        if not loose:
+            return
         for p in g["params"]:
             if id(p) in self._flat_ids or p.grad is None:
                 continue

@@ -132,6 +132,5 @@ class GraphedTrainStep:
         if whole:
             self.optimizer._flat_step += 1
         else:
-            self.reducer.reduce_flat()
-            self.optimizer.step()
+            self.reducer.reduce_flat_and_step()
         return self.losses, self.outputs

@@ -163,6 +163,62 @@ def test_gloo_world2_streamed_exchange_matches_global_batch_adamw(sharded):
     assert all(r[1] for r in res), res
 
 
+def _worker_flat_step(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coma_unet_amd import ops
+    from coma_unet_amd.optim import FusedAdamW
+    from coma_unet_amd.data_parallel import GradReducer, broadcast_module
+    ops.adamw_ = _cpu_adamw
+    torch.manual_seed(11)
+    net, ref = _Net(), _Net()
+    broadcast_module(net, src=0)
+    ref.load_state_dict(net.state_dict())
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2)
+    opt = FusedAdamW(net.parameters(), lr=1e-2)
+    red = GradReducer(opt, bucket_bytes=96)        # several buckets: the step is taken bucket by bucket
+    ok = True
+    for step in range(5):
+        g = torch.Generator().manual_seed(80 + step)
+        xs = [torch.randn((4, 7), generator=g) for _ in range(world)]
+        opt.zero_grad()
+        red.reset()
+        net(xs[rank]).sum().backward()
+        if step == 0:
+            red.finish()
+            opt.step()                             # builds the flat layout
+            red.overlap = False
+            red.remove_hooks()                     # what train.GraphedTrainStep does: hooks do not fire under replay
+        else:
+            before = opt._flat_step
+            red.reduce_flat_and_step()
+            ok &= opt._flat_step == before + 1 and len(range(0, opt.flat_g.numel(), red.bucket_elems)) > 2
+        ropt.zero_grad()
+        ref(torch.cat(xs)).sum().backward()
+        ropt.step()
+        for (n, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
+            ok &= bool(torch.allclose(a, b, rtol=1e-4, atol=1e-6))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_pipelined_allreduce_and_adamw_matches_global_batch():
+    """GradReducer.reduce_flat_and_step (bench.py's default N > 1 mode after the graph-replayed backward): bucket-wise
+    all-reduce with each bucket's AdamW slice taken as soon as its exchange is done == torch.optim.AdamW on the global batch."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_flat_step, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=60) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
 def _worker_rnc(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
