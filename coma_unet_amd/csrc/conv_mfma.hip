@@ -1254,6 +1254,266 @@ __global__ __launch_bounds__(256, 2) void conv_thin16_k(Thin16P p) {
 }
 
 // =====================================================================================
+// conv_thin16f_k -- the fp32 twin of conv_thin16_k (exact fp32: v_mfma_f32_16x16x4_f32): stride-1 3x3x3 forward /
+// data-gradient of the few-channel full-resolution layers on fp32 tensors (C <= 16, N <= 16, or C <= 8 and N <= 32).
+// In fp32 mode these ran on the 32x32x2 halo kernel with half of every tile zero padding (16 -> 16: 1.05 ms at 128^3) or on
+// the VALU kernels (16 -> 1: 0.94 ms, 3 -> 16 data-gradient: 0.94 ms).  K = 4 per MFMA stays inside one tap: the lane of
+// k group lg holds CP/4 consecutive channels of its voxel (ONE 16- or 8-byte LDS read per tap and voxel group) and feeds
+// element j of it to the tap's MFMA j; the weights (27 x 16 NB x CP floats, <= 27.6 KB) sit in LDS in the same order, one
+// read per tap shared by the wave's four voxel groups.  Staging, tile walk, epilogue and statistics as in conv_thin16_k.
+// =====================================================================================
+struct Thin16FP {
+  const float* x; int ldx; long sbx; int D, H, W, C;
+  float* y; int ldy; long sby; int N;
+  const float* w; long wsb;
+  const float* bias; int bsb;
+  int flip;
+  unsigned xbytes;
+  int ntx, nty, ntz, ids_total, ids_per_block;
+  int st16;            // output rows allow aligned 16-byte (4-channel) stores
+  double2* stats; int stats_inst;
+};
+
+template <int CP, int NB>      // CP = padded input channels (8 or 16), NB = 16-channel output blocks (1 or 2)
+__global__ __launch_bounds__(256, 2) void conv_thin16f_k(Thin16FP p) {
+  constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
+  constexpr int CQ = CP / 4;                    // channels per lane and tap = MFMAs per tap
+  constexpr int P = CP * 4;                     // LDS row pitch (bytes)
+  constexpr int PCH = CP / 4;                   // 16-byte pieces per halo row
+  constexpr int HP = HV * PCH, HIT = (HP + 255) / 256;
+  constexpr int WROW = NB * 16;                 // weight rows (output channels) per tap
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Hl = smem;                              // [HV][CP] floats
+  float* Wl = reinterpret_cast<float*>(smem + HV * P);     // [27][WROW][CP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z;
+  const int lv = lane & 15, lg = lane >> 4;
+  const float* xb = p.x + (long)b * p.sbx;
+  const float* wb = p.w + (long)b * p.wsb;
+  float* yb = p.y + (long)b * p.sby;
+
+  // ---- weights -> LDS (zero padded in n and c; `flip` mirrors the taps for the data-gradient) ----
+  for (int i = tid; i < 27 * WROW * CP; i += 256) {
+    const int c = i % CP, n = (i / CP) % WROW, t = i / (CP * WROW);
+    const int wt = p.flip ? 26 - t : t;
+    const bool ok = n < p.N && c < p.C;
+    const float v = wb[ok ? ((long)wt * p.N + n) * p.C + c : 0];
+    Wl[i] = ok ? v : 0.f;
+  }
+  // ---- fragment bases ----
+  const int gz = wid >> 1, gy0 = 2 * (wid & 1);
+  const int xbase = ((gz * HY + gy0) * HX + lv) * P + lg * CQ * 4;      // + tap offset + voxel-group offset
+  const int wbase = (lv * CP + lg * CQ) * 4;                            // + (tap * WROW + nb * 16) * CP * 4
+  // ---- staging descriptors ----
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, p.xbytes, 0x00020000);
+  constexpr unsigned OOB = 0x7fff0000u;
+  int h_z[HIT], h_y[HIT], h_x[HIT];
+  unsigned h_boff[HIT];
+#pragma unroll
+  for (int it = 0; it < HIT; ++it) {
+    const int piece = tid + 256 * it;
+    const int row = piece / PCH, ch = piece % PCH;
+    const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+    h_z[it] = piece < HP ? hz : (1 << 20); h_y[it] = hy; h_x[it] = hx;
+    h_boff[it] = (unsigned)((((hz * p.H + hy) * p.W + hx) * p.ldx + ch * 4) * 4);
+  }
+  // channels of this thread's pieces that belong to the tensor (a piece = 4 channels; the quarter is a per-thread constant)
+  const int nval = p.C - 4 * (tid % PCH);
+  const uint4 hmask = make_uint4(nval > 0 ? ~0u : 0u, nval > 1 ? ~0u : 0u, nval > 2 ? ~0u : 0u, nval > 3 ? ~0u : 0u);
+  uint4 hreg[HIT];
+  auto store_halo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it)
+      if (tid + 256 * it < HP) {
+        uint4 v = hreg[it];
+        v.x &= hmask.x; v.y &= hmask.y; v.z &= hmask.z; v.w &= hmask.w;
+        *reinterpret_cast<uint4*>(Hl + (tid + 256 * it) * 16) = v;
+      }
+  };
+
+  const int id_begin = xcd_remap(blockIdx.x, gridDim.x) * p.ids_per_block;
+  int id_end = id_begin + p.ids_per_block;
+  if (id_end > p.ids_total) id_end = p.ids_total;
+  int id = id_begin, tix = 0, tiy = 0, tiz = 0;
+  while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
+  const bool do_stats = p.stats != nullptr;
+  float st_s[NB][4], st_q[NB][4], bv[NB][4];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nb * 16 + 4 * lg + j;
+      st_s[nb][j] = 0.f; st_q[nb][j] = 0.f;
+      bv[nb][j] = (p.bias && n < p.N) ? p.bias[b * p.bsb + n] : 0.f;
+    }
+  if (id < id_end) {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      const int z0 = tiz * TZ, y0 = tiy * TY, x0 = tix * TX;
+      const bool ok = (unsigned)(z0 - 1 + h_z[it]) < (unsigned)p.D && (unsigned)(y0 - 1 + h_y[it]) < (unsigned)p.H &&
+                      (unsigned)(x0 - 1 + h_x[it]) < (unsigned)p.W;
+      const unsigned org_b = (unsigned)((((long)((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * p.ldx) * 4);
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? org_b + h_boff[it] : OOB, 0, 0);
+      hreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  while (id < id_end) {
+    const int x0 = tix * TX, y0 = tiy * TY, z0 = tiz * TZ;
+    int nid = id + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nid < id_end && !tile_coords(nid, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nid;
+    const bool has_next = nid < id_end;
+    const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, has_next ? p.xbytes : 0, 0x00020000);
+    __syncthreads();                       // the previous tile's fragment reads are done (first tile: the weight image is complete)
+    store_halo();
+    __syncthreads();
+    f32x4_t acc[4][NB];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[q][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // fragments one tap ahead (the four voxel groups' rows + the weights of the tap)
+    float xf[2][4][CQ], wfr[2][NB][CQ];
+    auto rd = [&](int t, int bf) __attribute__((always_inline)) {
+      const int toff = (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * P;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const char* src = Hl + xbase + toff + ((q >> 1) * HX + (q & 1) * 16) * P;
+        if constexpr (CQ == 4) { const float4 v = *reinterpret_cast<const float4*>(src); xf[bf][q][0] = v.x; xf[bf][q][1] = v.y; xf[bf][q][2] = v.z; xf[bf][q][3] = v.w; }
+        else { const float2 v = *reinterpret_cast<const float2*>(src); xf[bf][q][0] = v.x; xf[bf][q][1] = v.y; }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const char* src = reinterpret_cast<const char*>(Wl) + wbase + (t * WROW + nb * 16) * CP * 4;
+        if constexpr (CQ == 4) { const float4 v = *reinterpret_cast<const float4*>(src); wfr[bf][nb][0] = v.x; wfr[bf][nb][1] = v.y; wfr[bf][nb][2] = v.z; wfr[bf][nb][3] = v.w; }
+        else { const float2 v = *reinterpret_cast<const float2*>(src); wfr[bf][nb][0] = v.x; wfr[bf][nb][1] = v.y; }
+      }
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      if (t + 1 < 27) rd(t + 1, (t + 1) & 1);
+      if (t < HIT) {                       // one staging piece of the next tile per tap
+        const int it = t;
+        const bool ok = (unsigned)(ntiz * TZ - 1 + h_z[it]) < (unsigned)p.D && (unsigned)(ntiy * TY - 1 + h_y[it]) < (unsigned)p.H &&
+                        (unsigned)(ntix * TX - 1 + h_x[it]) < (unsigned)p.W;
+        const unsigned org_b = (unsigned)((((long)((ntiz * TZ - 1) * p.H + (ntiy * TY - 1)) * p.W + (ntix * TX - 1)) * p.ldx) * 4);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_n, ok ? org_b + h_boff[it] : OOB, 0, 0);
+        hreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < CQ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[q][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[t & 1][nb][j], xf[t & 1][q][j], acc[q][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(HIT <= 27, "one staging piece per tap");
+    // ---- epilogue: lane = voxel lv of group q, output channels nb*16 + 4 lg + 0..3 ----
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int vz = z0 + gz, vy = y0 + gy0 + (q >> 1), vx = x0 + (q & 1) * 16 + lv;
+      const bool valid = vz < p.D && vy < p.H && vx < p.W;
+      float* vox = yb + ((long)(vz * p.H + vy) * p.W + vx) * p.ldy;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = nb * 16 + 4 * lg;
+        if (n >= p.N) continue;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = acc[q][nb][j] + bv[nb][j];
+          if (do_stats) { const float r = valid ? o[j] : 0.f; st_s[nb][j] += r; st_q[nb][j] = fmaf(r, r, st_q[nb][j]); }
+        }
+        if (valid) {
+          if (p.st16 && n + 3 < p.N) *reinterpret_cast<float4*>(vox + n) = make_float4(o[0], o[1], o[2], o[3]);
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n + j < p.N) vox[n + j] = o[j];
+          }
+        }
+      }
+    }
+    id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
+  }
+  // ---- fused statistics (as conv_thin16_k) ----
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [4 waves][32 ch][2]
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = st_s[nb][j], c = st_q[nb][j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+        if (lv == 0) { red[(wid * 32 + nb * 16 + 4 * lg + j) * 2] = a; red[(wid * 32 + nb * 16 + 4 * lg + j) * 2 + 1] = c; }
+      }
+    __syncthreads();
+    if (tid < NB * 16 && tid < p.N) {
+      double a = 0.0, c = 0.0;
+      for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
+      const int G = p.stats_inst ? gridDim.z : 1;
+      const int g = p.stats_inst ? b : 0;
+      const int chunk = p.stats_inst ? blockIdx.x : blockIdx.x + gridDim.x * b;
+      p.stats[((long)chunk * G + g) * p.N + tid] = make_double2(a, c);
+    }
+  }
+}
+
+static bool aligned16(const void* p);
+static bool thin16f_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  static const bool on = []{ const char* e = getenv("COMA_THIN16F"); return !(e && e[0] == '0'); }();
+  return on && d->ksize == 3 && d->stride == 1 && x->dtype == COMA_F32 && y->dtype == COMA_F32 && x->W >= 32 && x->C <= 16 &&
+         y->C <= (x->C > 8 ? 16 : 32) && x->ld % 4 == 0 && x->sb % 4 == 0 && (!x->data || aligned16(x->data)) &&
+         (unsigned long long)t_vox(x) * x->ld * 4 < 0x7fff0000ull && (long)t_vox(y) * y->ld < (1L << 31);
+}
+
+static int conv_thin16f(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias, const coma_tensor* y,
+                        hipStream_t s, double2* stats, int stats_inst, int* stats_chunks) {
+  Thin16FP q;
+  q.x = (const float*)x->data; q.ldx = (int)x->ld; q.sbx = x->sb; q.D = x->D; q.H = x->H; q.W = x->W; q.C = x->C;
+  q.y = (float*)y->data; q.ldy = (int)y->ld; q.sby = y->sb; q.N = y->C;
+  q.w = (const float*)wk; q.wsb = d->per_sample_w ? 27L * y->C * x->C : 0;
+  q.bias = bias; q.bsb = d->per_sample_w ? y->C : 0;
+  q.flip = d->form == 1;
+  q.xbytes = (unsigned)((unsigned long long)t_vox(x) * x->ld * 4);
+  q.st16 = y->ld % 4 == 0 && y->sb % 4 == 0 && (((uintptr_t)y->data) & 15) == 0;
+  q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
+  q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
+  int gx = 512 / x->B;                                 // two blocks per CU, one round (a tile is 16x the bf16 MFMA time)
+  if (gx < 1) gx = 1;
+  if (gx > q.ids_total) gx = q.ids_total;
+  q.ids_per_block = (q.ids_total + gx - 1) / gx;
+  gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
+  q.stats = nullptr; q.stats_inst = stats_inst;
+  if (stats && gx * (stats_inst ? 1 : x->B) <= 1024 / (stats_inst ? x->B : 1)) {
+    q.stats = stats;
+    *stats_chunks = stats_inst ? gx : gx * x->B;
+  }
+  const dim3 grid((unsigned)gx, 1, (unsigned)x->B);
+  const bool c16 = q.C > 8, n32 = q.N > 16;
+  const int cp = c16 ? 16 : 8, wrow = n32 ? 32 : 16;
+  const size_t lds = (size_t)34 * 6 * 4 * cp * 4 + (size_t)27 * wrow * cp * 4;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_thin16f_k<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_thin16f_k<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_thin16f_k<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr = true;
+  }
+  coma_set_kernel_tag("conv_thin16f_k<%d, %d>", cp, n32 ? 2 : 1);
+  if (c16) hipLaunchKernelGGL((conv_thin16f_k<16, 1>), grid, dim3(256), lds, s, q);
+  else if (n32) hipLaunchKernelGGL((conv_thin16f_k<8, 2>), grid, dim3(256), lds, s, q);
+  else hipLaunchKernelGGL((conv_thin16f_k<8, 1>), grid, dim3(256), lds, s, q);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// =====================================================================================
 // conv_mfma_pw_k -- 1x1x1 convolution for small channel counts (8 <= C <= 64, N <= 64): the attention
 // gate's W_g / W_x (C -> C/2) and their data-gradients at full resolution.  HBM-bound: no LDS at all --
 // the weight fragments live in registers for the whole kernel, each lane streams 16-byte channel chunks
@@ -1413,6 +1673,7 @@ static bool f32_halo_ok(const coma_conv_desc* d, const coma_tensor* x, const com
 bool conv_f32mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (x->dtype != COMA_F32 || y->dtype != COMA_F32) return false;
   if ((long)t_vox(x) * x->ld >= (1L << 31) || (long)t_vox(y) * y->ld >= (1L << 31)) return false;
+  if (thin16f_ok(d, x, y)) return true;
   if (f32_halo_ok(d, x, y)) return true;
   if (x->C % 16 || y->C % 32) return false;
   if (x->ld % 4 || y->ld % 4 || x->sb % 4 || y->sb % 4) return false;
@@ -1621,7 +1882,7 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
 
 // bytes of workspace with which the deep layers' K loop may be split over more blocks (0: never split)
 size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
-  if (x->dtype == COMA_F32) { if (f32_halo_ok(d, x, y)) return 0; }
+  if (x->dtype == COMA_F32) { if (thin16f_ok(d, x, y) || f32_halo_ok(d, x, y)) return 0; }
   else if (halo_ok(d, x, y) || pw_ok(d, x, y)) return 0;
   return sizeof(float) * (size_t)y->B * t_vox(y) * y->C <= ((size_t)64 << 20) ? sizeof(float) * (size_t)y->B * t_vox(y) * y->C : 0;
 }
@@ -1630,6 +1891,7 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
                   const coma_tensor* y, hipStream_t s, double2* stats, int stats_inst, int* stats_chunks, void* ws,
                   size_t ws_bytes) {
   const bool f32 = x->dtype == COMA_F32;
+  if (f32 && thin16f_ok(d, x, y)) return conv_thin16f(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
   if (f32) { if (f32_halo_ok(d, x, y)) return conv_mfma_halo<float>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks); }
   else if (halo_ok(d, x, y)) return conv_mfma_halo<bf16_t>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
   if (!f32 && pw_ok(d, x, y) && !(x->C % 32 == 0 && y->C % 32 == 0 && x->C * y->C > 64 * 32)) {

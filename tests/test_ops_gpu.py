@@ -647,3 +647,62 @@ def test_roimse_voxel_wise_matches_oracle(dtype):
     assert abs(float(crit(pg, gt.cuda(), roi.cuda())) - float(lo.mean())) < 1e-5 * abs(float(lo.mean()))
     with pytest.raises(NotImplementedError):
         RoiMSE(w, ROI_INDICES, voxel_wise=True)        # no template and no data_util module: the reference's private file
+
+
+@pytest.mark.parametrize("mode", ["plain", "instance", "batch"])
+@pytest.mark.parametrize("case", THIN16_CASES[:12])
+def test_thin16f_kernel_fp32_fwd_dgrad_and_fused_stats(case, mode):
+    """conv_thin16f_k (exact fp32: v_mfma_f32_16x16x4_f32), the fp32 twin of the test above: fp32 tensors in pitch-8
+    buffers whose foreign lanes are NaN, forward / data-gradient against fp64 at fp32 accuracy, fused statistics."""
+    ops, L = _ops()
+    from coma_unet_amd._lib import lib
+    cin, cout, dims, per_sample = case
+    B, E, k = 2, 3, 3
+    g = torch.Generator().manual_seed(cin * 41 + cout + dims[2])
+    x = torch.randn((B, cin, *dims), generator=g).double()
+    if per_sample:
+        master = torch.randn((E, cout, cin, k, k, k), generator=g) * 0.2
+        r = torch.rand((B, E), generator=g)
+        wmix = torch.einsum("be,e...->b...", r.double(), master.double())
+        bias = torch.randn((B, cout), generator=g)
+    else:
+        master = torch.randn((cout, cin, k, k, k), generator=g) * 0.2
+        r = None
+        wmix = master.double().unsqueeze(0).expand(B, cout, cin, k, k, k)
+        bias = torch.randn((cout,), generator=g)
+    x = x.float().double()
+    xr = x.clone().requires_grad_(True)
+    yr = torch.cat([F.conv3d(xr[i:i + 1], wmix[i], (bias[i] if per_sample else bias).double(), padding=1) for i in range(B)], 0)
+    gy = torch.randn(yr.shape, generator=g).float().double()
+    yr.backward(gy)
+
+    def padded(t_ext):
+        v = to_int(t_ext).to("cuda", torch.float32)
+        C = v.shape[-1]
+        if C % 8 == 0:
+            return v
+        buf = torch.full(tuple(v.shape[:4]) + ((C + 7) // 8 * 8,), float("nan"), dtype=torch.float32, device="cuda")
+        buf[..., :C] = v
+        return buf[..., :C]
+
+    xi = padded(x)
+    rg = r.cuda() if per_sample else None
+    wk_f, wk_d = ops.PrepWeights.apply(master.cuda(), rg, False, torch.float32, torch.float32)
+    norm = None
+    if mode != "plain":
+        norm = (L.NORM_INSTANCE if mode == "instance" else L.NORM_BATCH, 1e-5, None, None, 0.1)
+    y, mean, rstd = ops._conv_fwd(xi, wk_f, bias.cuda(), k, 1, 0, per_sample, 0, None, norm)
+    assert lib.coma_last_kernel().decode().startswith("conv_thin16f_k"), lib.coma_last_kernel()
+    assert torch.isfinite(y).all() and rel(to_ext(y), yr) < 3e-6
+    if norm is not None:
+        yf = y.double()
+        red = (1, 2, 3) if mode == "instance" else (0, 1, 2, 3)
+        m_ref = yf.mean(red).reshape(mean.shape)
+        v_ref = yf.var(red, unbiased=False).reshape(mean.shape)
+        assert float((mean.double() - m_ref).abs().max()) < 1e-5 * (1.0 + float(m_ref.abs().max()))
+        assert rel(rstd.double(), (v_ref + 1e-5).rsqrt()) < 1e-5
+    if mode == "plain":
+        dyi = padded(gy)
+        dx, _, _ = ops._conv_bwd(xi, wk_d, dyi, k, 1, 0, per_sample, 0, None, True, False, 0, None)
+        assert cout > 16 or lib.coma_last_kernel().decode().startswith("conv_thin16f_k"), lib.coma_last_kernel()
+        assert torch.isfinite(dx).all() and rel(to_ext(dx), xr.grad) < 3e-6
