@@ -2620,6 +2620,227 @@ __global__ __launch_bounds__(256) void wgrad_replica_sum_k(const float* __restri
   out[i] = a;
 }
 
+// =====================================================================================
+// conv_thin16f_wgrad_k -- fp32 weight gradient of the few-channel full-resolution layers (stride-1 3x3x3, C <= 16,
+// N <= 16, or C <= 4 and N <= 32), exact fp32 on v_mfma_f32_16x16x4_f32 with the VOXELS along K:
+//   dW[tap][n][c] += dy[v][n] * x[v + tap][c]:  rows = 16 output channels (A = dy), columns = 16 = TPM taps x CP channels
+//   (B = x at the tap's offset: 27 / 14 / 7 column tiles for CP = 16 / 8 / 4), 4 voxels per MFMA.
+// A wave keeps ALL column tiles' accumulators (<= 108 VGPRs) and walks its 64 voxels of every tile in 16 steps; both
+// operands are one 4-byte LDS read per lane and MFMA (dense dy tile [256][16 NB], x halo [816][CP]).  The generic fp32
+// weight-gradient kernel spent 32 x 32 tiles on these layers: 16 -> 16 at 128^3 1.8 ms, 16 -> 1 1.8 ms, 8 -> 8 1.2 ms.
+// Blocks merge through LDS (ds_add) and then into one of `nrep` replicas with fp32 atomics.
+// =====================================================================================
+struct Thin16FWP {
+  const float* x; int ldx; long sbx; int D, H, W, C;
+  const float* dy; int ldn; long sbn; int N;
+  unsigned xbytes, dbytes;
+  int ntx, nty, ntz, ids_total, ids_per_block;
+  float* dwk; long wsb;
+  int nrep; long rep_stride;
+};
+
+template <int CP, int NB>      // (CP = 16: 27 column tiles = 108 accumulator registers + 68 of staged pieces: one block per CU)
+__global__ __launch_bounds__(256, CP == 16 ? 1 : 2) void conv_thin16f_wgrad_k(Thin16FWP p) {
+  constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ, TM = TX * TY * TZ;
+  constexpr int TPM = 16 / CP, NM = (27 + TPM - 1) / TPM;
+  constexpr int ND = NB * 16;                        // floats per dense dy row
+  constexpr int PCH = CP / 4, DCH = ND / 4;          // 16-byte pieces per halo / dense row
+  constexpr int HP = HV * PCH, DP = TM * DCH, HIT = (HP + 255) / 256, DIT = DP / 256, NIT = HIT + DIT;
+  static_assert(NIT <= 32, "two staging pieces per K step at most");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Hl = reinterpret_cast<float*>(smem);                      // [HV][CP]
+  float* Dl = Hl + HV * CP;                                        // [TM][ND]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z;
+  const int lv = lane & 15, lg = lane >> 4;
+  const float* xb = p.x + (long)b * p.sbx;
+  const float* db = p.dy + (long)b * p.sbn;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, p.dbytes, 0x00020000);
+  constexpr unsigned OOB = 0x7fff0000u;
+
+  // ---- staging descriptors: pieces 0..HIT-1 = x halo, HIT.. = dense dy ----
+  int s_z[NIT], s_y[NIT], s_x[NIT];
+  unsigned s_boff[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (it < HIT) {
+      const int piece = tid + 256 * it;
+      const int row = piece / PCH, ch = piece % PCH;
+      const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+      s_z[it] = piece < HP ? hz - 1 : (1 << 20); s_y[it] = hy - 1; s_x[it] = hx - 1;
+      s_boff[it] = (unsigned)(ch * 16);
+    } else {
+      const int piece = tid + 256 * (it - HIT);
+      const int row = piece / DCH, ch = piece % DCH;
+      s_z[it] = row >> 7; s_y[it] = (row >> 5) & 3; s_x[it] = row & 31;
+      s_boff[it] = (unsigned)(ch * 16);
+    }
+  }
+  const int xval = p.C - 4 * (tid % PCH), dval = p.N - 4 * (tid % DCH);
+  const uint4 xmask = make_uint4(xval > 0 ? ~0u : 0u, xval > 1 ? ~0u : 0u, xval > 2 ? ~0u : 0u, xval > 3 ? ~0u : 0u);
+  const uint4 dmask = make_uint4(dval > 0 ? ~0u : 0u, dval > 1 ? ~0u : 0u, dval > 2 ? ~0u : 0u, dval > 3 ? ~0u : 0u);
+  uint4 sreg[NIT];
+  auto issue = [&](int it, int z0, int y0, int x0, const __amdgpu_buffer_rsrc_t& rx, const __amdgpu_buffer_rsrc_t& rd) __attribute__((always_inline)) {
+    const int gz = z0 + s_z[it], gy = y0 + s_y[it], gx = x0 + s_x[it];
+    const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const int ld = it < HIT ? p.ldx : p.ldn;
+    const unsigned off = (unsigned)(((gz * p.H + gy) * p.W + gx) * ld) * 4u + s_boff[it];
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(it < HIT ? rx : rd, ok ? off : OOB, 0, 0);
+    sreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      uint4 v = sreg[it];
+      if (it < HIT) {
+        if (tid + 256 * it < HP) {
+          v.x &= xmask.x; v.y &= xmask.y; v.z &= xmask.z; v.w &= xmask.w;
+          reinterpret_cast<uint4*>(Hl)[tid + 256 * it] = v;
+        }
+      } else {
+        v.x &= dmask.x; v.y &= dmask.y; v.z &= dmask.z; v.w &= dmask.w;
+        reinterpret_cast<uint4*>(Dl)[tid + 256 * (it - HIT)] = v;
+      }
+    }
+  };
+
+  // ---- fragment addressing (floats): this wave's 64 voxels = rows (gz, gy0 + {0, 1}), K step s = voxels 4 s + lg ----
+  const int gz = wid >> 1, gy0 = 2 * (wid & 1);
+  const int dbase = ((gz * 4 + gy0) * 32 + lg) * ND + lv;                       // + step offset, + nb * 16
+  const int sub = lv / CP, cc = lv % CP;
+  const int xbase = ((gz * HY + gy0) * HX + lg) * CP + cc;                      // + step offset + tap offset
+  int toff[NM];                                                                  // (CP = 16: compile-time constants)
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int t = TPM == 1 ? m : (m * TPM + sub < 27 ? m * TPM + sub : 0);
+    toff[m] = (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * CP;
+  }
+  f32x4_t acc[NM][NB];
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[m][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int id_begin = xcd_remap(blockIdx.x, gridDim.x) * p.ids_per_block;
+  int id_end = id_begin + p.ids_per_block;
+  if (id_end > p.ids_total) id_end = p.ids_total;
+  int id = id_begin, tix = 0, tiy = 0, tiz = 0;
+  while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
+  if (id < id_end) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) issue(it, tiz * TZ, tiy * TY, tix * TX, rs_x, rs_d);
+  }
+  while (id < id_end) {
+    int nid = id + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nid < id_end && !tile_coords(nid, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nid;
+    const bool has_next = nid < id_end;
+    const __amdgpu_buffer_rsrc_t rn_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, has_next ? p.xbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, has_next ? p.dbytes : 0, 0x00020000);
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    float af[2][NB], bf[2][NM];
+    auto rd = [&](int s_, int buf) __attribute__((always_inline)) {
+      const int so_d = ((s_ >> 3) * 32 + 4 * (s_ & 7)) * ND, so_x = ((s_ >> 3) * HX + 4 * (s_ & 7)) * CP;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) af[buf][nb] = Dl[dbase + so_d + nb * 16];
+#pragma unroll
+      for (int m = 0; m < NM; ++m) bf[buf][m] = Hl[xbase + so_x + toff[m]];
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      if (s_ + 1 < 16) rd(s_ + 1, (s_ + 1) & 1);
+      if (s_ < NIT) issue(s_, ntiz * TZ, ntiy * TY, ntix * TX, rn_x, rn_d);
+      if (s_ + 16 < NIT) issue(s_ + 16, ntiz * TZ, ntiy * TY, ntix * TX, rn_x, rn_d);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s_ & 1][nb], bf[s_ & 1][m], acc[m][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
+  }
+  // ---- merge: the four waves' tiles add up in LDS, then one fp32 atomic per weight into this block's replica ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);                     // [NM][NB][16 n][16 col]
+  for (int i = tid; i < NM * NB * 256; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(&red[((m * NB + nb) * 16 + 4 * lg + j) * 16 + lv], acc[m][nb][j]);
+  __syncthreads();
+  float* wout = p.dwk + (long)b * p.wsb + (long)(blockIdx.x % (unsigned)p.nrep) * p.rep_stride;
+  for (int i = tid; i < NM * NB * 256; i += 256) {
+    const int col = i & 15, row = (i >> 4) & 15, nb = (i >> 8) % NB, m = i / (256 * NB);
+    const int tap = m * TPM + col / CP, c = col % CP, n = nb * 16 + row;
+    if (tap < 27 && n < p.N && c < p.C) atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, red[i]);
+  }
+}
+
+static bool thin16f_wgrad_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  static const bool on = []{ const char* e = getenv("COMA_THIN16F"); return !(e && e[0] == '0'); }();
+  const int nmax = x->C <= 4 ? 32 : 16;
+  return on && d->form == 0 && d->ksize == 3 && d->stride == 1 && x->dtype == COMA_F32 && dy->dtype == COMA_F32 && x->W >= 32 &&
+         x->C <= 16 && dy->C <= nmax && x->ld % 4 == 0 && x->sb % 4 == 0 && dy->ld % 4 == 0 && dy->sb % 4 == 0 &&
+         (!x->data || aligned16(x->data)) && (!dy->data || aligned16(dy->data)) &&
+         (unsigned long long)t_vox(x) * x->ld * 4 < 0x7fff0000ull && (unsigned long long)t_vox(dy) * dy->ld * 4 < 0x7fff0000ull;
+}
+
+static int conv_thin16f_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws,
+                              size_t ws_bytes, hipStream_t s) {
+  Thin16FWP q;
+  q.x = (const float*)x->data; q.ldx = (int)x->ld; q.sbx = x->sb; q.D = x->D; q.H = x->H; q.W = x->W; q.C = x->C;
+  q.dy = (const float*)dy->data; q.ldn = (int)dy->ld; q.sbn = dy->sb; q.N = dy->C;
+  q.xbytes = (unsigned)((unsigned long long)t_vox(x) * x->ld * 4);
+  q.dbytes = (unsigned)((unsigned long long)t_vox(dy) * dy->ld * 4);
+  q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
+  q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
+  int gx = (q.C > 8 ? 256 : 512) / x->B;
+  if (gx < 1) gx = 1;
+  if (gx > q.ids_total) gx = q.ids_total;
+  q.ids_per_block = (q.ids_total + gx - 1) / gx;
+  gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
+  const long wsz1 = 27L * q.N * q.C, wsz = wsz1 * (d->per_sample_w ? x->B : 1);
+  q.wsb = d->per_sample_w ? wsz1 : 0;
+  const bool replicas = wsz <= WGRAD_REP_MAX_ELEMS && ws && ws_bytes >= sizeof(float) * wsz * WGRAD_NREP;
+  q.nrep = replicas ? WGRAD_NREP : 1;
+  q.rep_stride = replicas ? wsz : 0;
+  q.dwk = replicas ? (float*)ws : dwk;
+  if (hipMemsetAsync(q.dwk, 0, sizeof(float) * wsz * q.nrep, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  const int cp = q.C > 8 ? 16 : q.C > 4 ? 8 : 4, nb = q.N > 16 ? 2 : 1;
+  const int nm = (27 + 16 / cp - 1) / (16 / cp);
+  size_t lds = (size_t)34 * 6 * 4 * cp * 4 + (size_t)256 * nb * 16 * 4;
+  if (lds < (size_t)nm * nb * 256 * 4) lds = (size_t)nm * nb * 256 * 4;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_thin16f_wgrad_k<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_thin16f_wgrad_k<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_thin16f_wgrad_k<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_thin16f_wgrad_k<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr = true;
+  }
+  const dim3 grid((unsigned)gx, 1, (unsigned)x->B);
+  coma_set_kernel_tag("conv_thin16f_wgrad_k<%d, %d>", cp, nb);
+  if (cp == 16) hipLaunchKernelGGL((conv_thin16f_wgrad_k<16, 1>), grid, dim3(256), lds, s, q);
+  else if (cp == 8) hipLaunchKernelGGL((conv_thin16f_wgrad_k<8, 1>), grid, dim3(256), lds, s, q);
+  else if (nb == 2) hipLaunchKernelGGL((conv_thin16f_wgrad_k<4, 2>), grid, dim3(256), lds, s, q);
+  else hipLaunchKernelGGL((conv_thin16f_wgrad_k<4, 1>), grid, dim3(256), lds, s, q);
+  COMA_LAUNCH_CHECK();
+  if (replicas) {
+    hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
+    COMA_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws,
                             size_t ws_bytes, hipStream_t s) {
   Wgrad2P p;
@@ -2763,7 +2984,7 @@ static WgradPlan wgrad_plan(const coma_conv_desc* d, const coma_tensor* x, const
 }
 
 bool conv_mfma_wgrad_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
-  return wgrad2_ok(d, x, dy) || wgrad_plan(d, x, dy).ok;      // (bf16 and fp32: the plan checks the dtype pair)
+  return wgrad2_ok(d, x, dy) || thin16f_wgrad_ok(d, x, dy) || wgrad_plan(d, x, dy).ok;      // (bf16 and fp32: the plan checks the dtype pair)
 }
 size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   const long wsz = wgrad_out_elems(d, x, dy);
@@ -2773,6 +2994,7 @@ size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, c
 int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws, size_t ws_bytes,
                     hipStream_t s) {
   if (wgrad2_ok(d, x, dy)) return conv_mfma_wgrad2(d, x, dy, dwk, ws, ws_bytes, s);
+  if (thin16f_wgrad_ok(d, x, dy)) return conv_thin16f_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
   WgradPlan pl = wgrad_plan(d, x, dy);
   COMA_CHECK(pl.ok, "conv_mfma_wgrad: unsupported problem");
   pl.p.dwk = dwk;

@@ -672,7 +672,8 @@ def test_thin16f_kernel_fp32_fwd_dgrad_and_fused_stats(case, mode):
         bias = torch.randn((cout,), generator=g)
     x = x.float().double()
     xr = x.clone().requires_grad_(True)
-    yr = torch.cat([F.conv3d(xr[i:i + 1], wmix[i], (bias[i] if per_sample else bias).double(), padding=1) for i in range(B)], 0)
+    wr = wmix.float().double().clone().requires_grad_(True)
+    yr = torch.cat([F.conv3d(xr[i:i + 1], wr[i], (bias[i] if per_sample else bias).double(), padding=1) for i in range(B)], 0)
     gy = torch.randn(yr.shape, generator=g).float().double()
     yr.backward(gy)
 
@@ -706,3 +707,11 @@ def test_thin16f_kernel_fp32_fwd_dgrad_and_fused_stats(case, mode):
         dx, _, _ = ops._conv_bwd(xi, wk_d, dyi, k, 1, 0, per_sample, 0, None, True, False, 0, None)
         assert cout > 16 or lib.coma_last_kernel().decode().startswith("conv_thin16f_k"), lib.coma_last_kernel()
         assert torch.isfinite(dx).all() and rel(to_ext(dx), xr.grad) < 3e-6
+        # weight gradient (kernel layout [Bw, taps, cout, cin]) on the voxels-along-K fp32 MFMA kernel
+        _, dwk, _ = ops._conv_bwd(xi, wk_d, dyi, k, 1, 0, per_sample, 0, tuple(wk_f.shape), False, True, 0, None)
+        assert lib.coma_last_kernel().decode().startswith("wgrad_replica_sum_k") or \
+            lib.coma_last_kernel().decode().startswith("conv_thin16f_wgrad_k"), lib.coma_last_kernel()
+        gw = wr.grad.reshape(B, cout, cin, 27).permute(0, 3, 1, 2)
+        if not per_sample:
+            gw = gw.sum(0, keepdim=True)
+        assert torch.isfinite(dwk).all() and rel(dwk, gw) < 2e-5, rel(dwk, gw)
