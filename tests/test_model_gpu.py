@@ -413,6 +413,25 @@ def test_side_stream_weight_preparation_equals_one_stream():
         assert rel(g, ref_g) < 5e-3 and torch.equal(p_, ref_p), (mode, rel(g, ref_g))      # (norm / loss reductions use fp32 atomics)
 
 
+def _grad_scale(model):
+    return {n: (float(p.grad.abs().max()) if p.grad is not None else 0.0) for n, p in model.named_parameters()}
+
+
+def _same_step(model, ref_params, ref_gscale, rtol=5e-3):
+    """Parameters after 'one more step from the same state' in two runs must agree to rtol -- except tensors whose gradient
+    is rounding noise or exactly zero depending on the run (the projection heads' BatchNorm behind an RnC loss that is
+    identically zero at batch 2: |g| <= 1e-6 of the largest gradient): Adam turns such a gradient into a step of ~lr in a
+    direction the fp32 atomics' order decides, or into no step at all."""
+    gmax = max(ref_gscale.values())
+    worst = (0.0, "")
+    for n, p in model.named_parameters():
+        r = ref_params[n]
+        if float(r.abs().max()) == 0 or ref_gscale[n] <= 1e-6 * gmax:
+            continue
+        worst = max(worst, (rel(p, r), n))
+    assert worst[0] < rtol, worst
+
+
 def test_checkpoint_roundtrip_and_plateau_scheduler(tmp_path):
     """ReduceLROnPlateau drives FusedAdamW (eager and graph-replayed: a learning-rate change re-captures),
     and a checkpoint in the reference's format (attn_unet_data_parallel.py:943-955) restores model, moments, step count
@@ -451,6 +470,7 @@ def test_checkpoint_roundtrip_and_plateau_scheduler(tmp_path):
     assert set(st0) == {"step", "exp_avg", "exp_avg_sq"} and float(st0["step"]) == 3.0
     next_loss = float(train_step(gm, crit, opt, gb)[0][0])            # step 4 of the original run (lr 5e-4)
     after4 = {n: p.detach().clone() for n, p in gm.named_parameters()}
+    gscale4 = _grad_scale(gm)
 
     gm2, gb2, opt2, sched2 = fresh()
     for _ in range(2):                     # the flat optimizer layout exists after the first steps; then restore
@@ -459,8 +479,7 @@ def test_checkpoint_roundtrip_and_plateau_scheduler(tmp_path):
     assert opt2.param_groups[0]["lr"] == 5e-4 and sched2.state_dict()["best"] == sched.state_dict()["best"]
     l2 = float(train_step(gm2, crit, opt2, gb2)[0][0])
     assert abs(l2 - next_loss) <= 1e-3 * abs(next_loss)
-    worst = max(rel(p, after4[n]) for n, p in gm2.named_parameters() if float(after4[n].abs().max()) > 0)
-    assert worst < 5e-3, worst             # same step from the same state (atomics order differs run to run)
+    _same_step(gm2, after4, gscale4)          # same step from the same state (atomics order differs run to run)
 
     # graph replay follows a scheduler change by re-capturing
     gm3, gb3, opt3, sched3 = fresh()
@@ -503,6 +522,7 @@ def test_resume_into_fresh_optimizer_matches_uninterrupted_run(tmp_path):
     m_norm = float(opt.flat_m.norm())
     l4 = float(train_step(gm, crit, opt, gb)[0][0])                      # step 4, uninterrupted
     after4 = {n: p.detach().clone() for n, p in gm.named_parameters()}
+    gscale4 = _grad_scale(gm)
 
     gm2, gb2, opt2 = fresh(99)                                           # different init: everything must come from the file
     checkpoint.load_checkpoint(files[0], gm2, opt2, None)                # BEFORE any step: no flat layout yet
@@ -511,8 +531,7 @@ def test_resume_into_fresh_optimizer_matches_uninterrupted_run(tmp_path):
     assert opt2.built and opt2._flat_step == 4 and int(opt2._step_dev) == 4
     assert not any(opt2.state[p] for p in opt2._flat_params if p in opt2.state)      # no dead fp32 clones left behind
     assert abs(l4b - l4) <= 1e-3 * abs(l4)
-    worst = max(rel(p, after4[n]) for n, p in gm2.named_parameters() if float(after4[n].abs().max()) > 0)
-    assert worst < 5e-3, worst      # with zeroed moments / step = 1 the first Adam step is ~lr everywhere: > 1e-1 on small tensors
+    _same_step(gm2, after4, gscale4)   # with zeroed moments / step = 1 the first Adam step is ~lr everywhere: > 1e-1 on small tensors
     assert abs(float(opt2.state_dict()["state"][0]["step"]) - 4.0) == 0
 
     # a stock torch.optim.AdamW state_dict (same param order) loads into a fresh FusedAdamW the same way
