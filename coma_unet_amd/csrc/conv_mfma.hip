@@ -1380,13 +1380,15 @@ __global__ __launch_bounds__(256, 2) void conv_thin16f_k(Thin16FP p) {
       for (int q = 0; q < 4; ++q) {
         const char* src = Hl + xbase + toff + ((q >> 1) * HX + (q & 1) * 16) * P;
         if constexpr (CQ == 4) { const float4 v = *reinterpret_cast<const float4*>(src); xf[bf][q][0] = v.x; xf[bf][q][1] = v.y; xf[bf][q][2] = v.z; xf[bf][q][3] = v.w; }
-        else { const float2 v = *reinterpret_cast<const float2*>(src); xf[bf][q][0] = v.x; xf[bf][q][1] = v.y; }
+        else if constexpr (CQ == 2) { const float2 v = *reinterpret_cast<const float2*>(src); xf[bf][q][0] = v.x; xf[bf][q][1] = v.y; }
+        else xf[bf][q][0] = *reinterpret_cast<const float*>(src);
       }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const char* src = reinterpret_cast<const char*>(Wl) + wbase + (t * WROW + nb * 16) * CP * 4;
         if constexpr (CQ == 4) { const float4 v = *reinterpret_cast<const float4*>(src); wfr[bf][nb][0] = v.x; wfr[bf][nb][1] = v.y; wfr[bf][nb][2] = v.z; wfr[bf][nb][3] = v.w; }
-        else { const float2 v = *reinterpret_cast<const float2*>(src); wfr[bf][nb][0] = v.x; wfr[bf][nb][1] = v.y; }
+        else if constexpr (CQ == 2) { const float2 v = *reinterpret_cast<const float2*>(src); wfr[bf][nb][0] = v.x; wfr[bf][nb][1] = v.y; }
+        else wfr[bf][nb][0] = *reinterpret_cast<const float*>(src);
       }
     };
     rd(0, 0);
@@ -1496,19 +1498,21 @@ static int conv_thin16f(const coma_conv_desc* d, const coma_tensor* x, const voi
   }
   const dim3 grid((unsigned)gx, 1, (unsigned)x->B);
   const bool c16 = q.C > 8, n32 = q.N > 16;
-  const int cp = c16 ? 16 : 8, wrow = n32 ? 32 : 16;
+  const int cp = c16 ? 16 : q.C > 4 ? 8 : 4, wrow = n32 ? 32 : 16;      // (C <= 4: one MFMA per tap)
   const size_t lds = (size_t)34 * 6 * 4 * cp * 4 + (size_t)27 * wrow * cp * 4;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_thin16f_k<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_thin16f_k<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_thin16f_k<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_thin16f_k<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_thin16f_k<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr = true;
   }
   coma_set_kernel_tag("conv_thin16f_k<%d, %d>", cp, n32 ? 2 : 1);
   if (c16) hipLaunchKernelGGL((conv_thin16f_k<16, 1>), grid, dim3(256), lds, s, q);
-  else if (n32) hipLaunchKernelGGL((conv_thin16f_k<8, 2>), grid, dim3(256), lds, s, q);
-  else hipLaunchKernelGGL((conv_thin16f_k<8, 1>), grid, dim3(256), lds, s, q);
+  else if (cp == 8) { if (n32) hipLaunchKernelGGL((conv_thin16f_k<8, 2>), grid, dim3(256), lds, s, q); else hipLaunchKernelGGL((conv_thin16f_k<8, 1>), grid, dim3(256), lds, s, q); }
+  else { if (n32) hipLaunchKernelGGL((conv_thin16f_k<4, 2>), grid, dim3(256), lds, s, q); else hipLaunchKernelGGL((conv_thin16f_k<4, 1>), grid, dim3(256), lds, s, q); }
   COMA_LAUNCH_CHECK();
   return 0;
 }
