@@ -2789,6 +2789,228 @@ __global__ __launch_bounds__(256, CP == 16 ? 1 : 2) void conv_thin16f_wgrad_k(Th
   }
 }
 
+// =====================================================================================
+// conv_thin16_wgrad_k -- bf16 weight gradient of the few-channel full-resolution layers (stride-1 3x3x3, C <= 16, N <= 16,
+// or C <= 8 and N <= 32) on v_mfma_f32_16x16x32_bf16 with the VOXELS along K (the structure of conv_thin16f_wgrad_k):
+// rows = 16 output channels, columns = 16 = TPM taps x CP channels (27 / 14 column tiles), 32 voxels per MFMA.  Both
+// operands are voxel-major in LDS (dense dy tile [256][16 NB], x halo [816][CP]) and are read TRANSPOSED with
+// ds_read_b64_tr_b16: a 16-lane group fetches 4 voxels x 16 columns, lane 4q+p supplying the address of voxel q, columns
+// 4p..4p+3 -- so for CP = 8 the lanes p = 2, 3 simply point at the next tap's rows.  K index 8g+j <-> voxel x = 4g+j (j < 4),
+// 16+4g+(j-4): the two 16-lane groups of a 32-lane half then read 8 consecutive 32-byte rows (conflict-free).
+// The 32x32x16 kernel it replaces here packed 2 or 4 taps into 32 columns and padded N to 32: 16 -> 16 at 128^3 212 us.
+// =====================================================================================
+struct Thin16WP {
+  const bf16_t* x; int ldx; long sbx; int D, H, W, C;
+  const bf16_t* dy; int ldn; long sbn; int N;
+  unsigned xbytes, dbytes;
+  int ntx, nty, ntz, ids_total, ids_per_block;
+  float* dwk; long wsb;
+  int nrep; long rep_stride;
+};
+
+template <int CP, int NB>
+__global__ __launch_bounds__(256, 2) void conv_thin16_wgrad_k(Thin16WP p) {
+  constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ, TM = TX * TY * TZ;
+  constexpr int TPM = 16 / CP, NM = (27 + TPM - 1) / TPM;
+  constexpr int ND = NB * 16;                        // bf16 per dense dy row
+  constexpr int PX = CP * 2, PD = ND * 2;            // row pitches (bytes)
+  constexpr int PCH = CP / 8, DCH = ND / 8;          // 16-byte pieces per halo / dense row
+  constexpr int HP = HV * PCH, DP = TM * DCH, HIT = (HP + 255) / 256, DIT = DP / 256, NIT = HIT + DIT;
+  constexpr int RING = 8;                            // B fragments in flight
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Hl = smem;                                   // [HV][CP]
+  char* Dl = smem + (HV + 2) * PX;                   // [TM][ND]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z;
+  const int lv = lane & 15, lg = lane >> 4;
+  const bf16_t* xb = p.x + (long)b * p.sbx;
+  const bf16_t* db = p.dy + (long)b * p.sbn;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xb), 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(db), 0, p.dbytes, 0x00020000);
+  constexpr unsigned OOB = 0x7fff0000u;
+
+  int s_z[NIT], s_y[NIT], s_x[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (it < HIT) {
+      const int piece = tid + 256 * it;
+      const int row = piece / PCH;
+      const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+      s_z[it] = piece < HP ? hz - 1 : (1 << 20); s_y[it] = hy - 1; s_x[it] = hx - 1;
+    } else {
+      const int row = (tid + 256 * (it - HIT)) / DCH;
+      s_z[it] = row >> 7; s_y[it] = (row >> 5) & 3; s_x[it] = row & 31;
+    }
+  }
+  const unsigned xoffb = (unsigned)((tid % PCH) * 16), doffb = (unsigned)((tid % DCH) * 16);
+  const uint4 xmask = mask8(p.C - 8 * (tid % PCH)), dmask = mask8(p.N - 8 * (tid % DCH));
+  uint4 sreg[NIT];
+  auto issue = [&](int it, int z0, int y0, int x0, const __amdgpu_buffer_rsrc_t& rx, const __amdgpu_buffer_rsrc_t& rd) __attribute__((always_inline)) {
+    const int gz = z0 + s_z[it], gy = y0 + s_y[it], gx = x0 + s_x[it];
+    const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const unsigned off = (unsigned)(((gz * p.H + gy) * p.W + gx) * (it < HIT ? p.ldx : p.ldn)) * 2u + (it < HIT ? xoffb : doffb);
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(it < HIT ? rx : rd, ok ? off : OOB, 0, 0);
+    sreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      uint4 v = sreg[it];
+      if (it < HIT) {
+        if (tid + 256 * it < HP) {
+          v.x &= xmask.x; v.y &= xmask.y; v.z &= xmask.z; v.w &= xmask.w;
+          reinterpret_cast<uint4*>(Hl)[tid + 256 * it] = v;
+        }
+      } else {
+        v.x &= dmask.x; v.y &= dmask.y; v.z &= dmask.z; v.w &= dmask.w;
+        reinterpret_cast<uint4*>(Dl)[tid + 256 * (it - HIT)] = v;
+      }
+    }
+  };
+
+  // ---- transposed-read addressing: lane 4q+p of group lg supplies voxel x = 4 lg + q (+16 for the second read), columns 4p.. ----
+  const int gz = wid >> 1, gy0 = 2 * (wid & 1);
+  const int q4 = lv >> 2, p4 = lv & 3;
+  const int vx = 4 * lg + q4;
+  const int d_addr = ((gz * 4 + gy0) * 32 + vx) * PD + 8 * p4;                                   // + row step s * 32 * PD, + 16 * PD second read, + nb * 32 bytes
+  const int sub = (4 * p4) / CP, cin = (4 * p4) % CP;
+  const int x_addr = ((gz * HY + gy0) * HX + vx) * PX + cin * 2;                                 // + s * HX * PX, + 16 * PX second read, + tap offset
+  int toff[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int t = TPM == 1 ? m : (m * TPM + sub < 27 ? m * TPM + sub : 0);    // (padding taps read tap 0: their columns are never stored)
+    toff[m] = (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * PX;
+  }
+  f32x4_t acc[NM][NB];
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[m][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int id_begin = xcd_remap(blockIdx.x, gridDim.x) * p.ids_per_block;
+  int id_end = id_begin + p.ids_per_block;
+  if (id_end > p.ids_total) id_end = p.ids_total;
+  int id = id_begin, tix = 0, tiy = 0, tiz = 0;
+  while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
+  if (id < id_end) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) issue(it, tiz * TZ, tiy * TY, tix * TX, rs_x, rs_d);
+  }
+  while (id < id_end) {
+    int nid = id + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nid < id_end && !tile_coords(nid, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nid;
+    const bool has_next = nid < id_end;
+    const __amdgpu_buffer_rsrc_t rn_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xb), 0, has_next ? p.xbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(db), 0, has_next ? p.dbytes : 0, 0x00020000);
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    // the sequence of (row step s, column tile m) pairs is unrolled; B fragments run RING pairs ahead
+    constexpr int NPAIR = 2 * NM;
+    bf16x8_t bring[RING];
+    auto rdb = [&](int pi) __attribute__((always_inline)) -> bf16x8_t {
+      const int s_ = pi / NM, m = pi % NM;
+      const char* src = Hl + x_addr + s_ * HX * PX + toff[m];
+      const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src));
+      const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src + 16 * PX));
+      return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto rda = [&](int s_, int nb) __attribute__((always_inline)) -> bf16x8_t {
+      const char* src = Dl + d_addr + s_ * 32 * PD + nb * 32;
+      const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src));
+      const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src + 16 * PD));
+      return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    bf16x8_t afr[2][NB];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) afr[s_][nb] = rda(s_, nb);
+#pragma unroll
+    for (int pi = 0; pi < RING && pi < NPAIR; ++pi) bring[pi] = rdb(pi);
+#pragma unroll
+    for (int pi = 0; pi < NPAIR; ++pi) {
+      const int s_ = pi / NM, m = pi % NM;
+      const bf16x8_t bcur = bring[pi % RING];
+      if (pi + RING < NPAIR) bring[pi % RING] = rdb(pi + RING);
+      if (pi < NIT) issue(pi, ntiz * TZ, ntiy * TY, ntix * TX, rn_x, rn_d);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[s_][nb], bcur, acc[m][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(NIT <= NPAIR, "one staging piece per MFMA step");
+    id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
+  }
+  // ---- merge (as conv_thin16f_wgrad_k) ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);                     // [NM][NB][16 n][16 col]
+  for (int i = tid; i < NM * NB * 256; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(&red[((m * NB + nb) * 16 + 4 * lg + j) * 16 + lv], acc[m][nb][j]);
+  __syncthreads();
+  float* wout = p.dwk + (long)b * p.wsb + (long)(blockIdx.x % (unsigned)p.nrep) * p.rep_stride;
+  for (int i = tid; i < NM * NB * 256; i += 256) {
+    const int col = i & 15, row = (i >> 4) & 15, nb = (i >> 8) % NB, m = i / (256 * NB);
+    const int tap = m * TPM + col / CP, c = col % CP, n = nb * 16 + row;
+    if (tap < 27 && n < p.N && c < p.C) atomicAdd(wout + ((long)tap * p.N + n) * p.C + c, red[i]);
+  }
+}
+
+static bool thin16_wgrad_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  static const bool on = []{ const char* e = getenv("COMA_THIN16W"); return !(e && e[0] == '0'); }();
+  const int nmax = x->C <= 8 ? 32 : 16;
+  return on && d->form == 0 && d->ksize == 3 && d->stride == 1 && x->dtype == COMA_BF16 && dy->dtype == COMA_BF16 && x->W >= 32 &&
+         x->C <= 16 && dy->C <= nmax && x->ld % 8 == 0 && x->sb % 8 == 0 && dy->ld % 8 == 0 && dy->sb % 8 == 0 &&
+         (!x->data || aligned16(x->data)) && (!dy->data || aligned16(dy->data)) &&
+         (unsigned long long)t_vox(x) * x->ld * 2 < 0x7fff0000ull && (unsigned long long)t_vox(dy) * dy->ld * 2 < 0x7fff0000ull;
+}
+
+static int conv_thin16_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws,
+                             size_t ws_bytes, hipStream_t s) {
+  Thin16WP q;
+  q.x = (const bf16_t*)x->data; q.ldx = (int)x->ld; q.sbx = x->sb; q.D = x->D; q.H = x->H; q.W = x->W; q.C = x->C;
+  q.dy = (const bf16_t*)dy->data; q.ldn = (int)dy->ld; q.sbn = dy->sb; q.N = dy->C;
+  q.xbytes = (unsigned)((unsigned long long)t_vox(x) * x->ld * 2);
+  q.dbytes = (unsigned)((unsigned long long)t_vox(dy) * dy->ld * 2);
+  q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
+  q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
+  int gx = 512 / x->B;
+  if (gx < 1) gx = 1;
+  if (gx > q.ids_total) gx = q.ids_total;
+  q.ids_per_block = (q.ids_total + gx - 1) / gx;
+  gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
+  const long wsz1 = 27L * q.N * q.C, wsz = wsz1 * (d->per_sample_w ? x->B : 1);
+  q.wsb = d->per_sample_w ? wsz1 : 0;
+  const bool replicas = wsz <= WGRAD_REP_MAX_ELEMS && ws && ws_bytes >= sizeof(float) * wsz * WGRAD_NREP;
+  q.nrep = replicas ? WGRAD_NREP : 1;
+  q.rep_stride = replicas ? wsz : 0;
+  q.dwk = replicas ? (float*)ws : dwk;
+  if (hipMemsetAsync(q.dwk, 0, sizeof(float) * wsz * q.nrep, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  const int cp = q.C > 8 ? 16 : 8, nb = q.N > 16 ? 2 : 1;
+  const int nm = cp == 16 ? 27 : 14;
+  size_t lds = (size_t)(34 * 6 * 4 + 2) * cp * 2 + (size_t)256 * nb * 16 * 2;
+  if (lds < (size_t)nm * nb * 256 * 4) lds = (size_t)nm * nb * 256 * 4;
+  const dim3 grid((unsigned)gx, 1, (unsigned)x->B);
+  coma_set_kernel_tag("conv_thin16_wgrad_k<%d, %d>", cp, nb);
+  if (cp == 16) hipLaunchKernelGGL((conv_thin16_wgrad_k<16, 1>), grid, dim3(256), lds, s, q);
+  else if (nb == 2) hipLaunchKernelGGL((conv_thin16_wgrad_k<8, 2>), grid, dim3(256), lds, s, q);
+  else hipLaunchKernelGGL((conv_thin16_wgrad_k<8, 1>), grid, dim3(256), lds, s, q);
+  COMA_LAUNCH_CHECK();
+  if (replicas) {
+    hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
+    COMA_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 static bool thin16f_wgrad_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   static const bool on = []{ const char* e = getenv("COMA_THIN16F"); return !(e && e[0] == '0'); }();
   const int nmax = x->C <= 4 ? 32 : 16;
@@ -2997,6 +3219,7 @@ size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, c
 
 int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws, size_t ws_bytes,
                     hipStream_t s) {
+  if (thin16_wgrad_ok(d, x, dy)) return conv_thin16_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
   if (wgrad2_ok(d, x, dy)) return conv_mfma_wgrad2(d, x, dy, dwk, ws, ws_bytes, s);
   if (thin16f_wgrad_ok(d, x, dy)) return conv_thin16f_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
   WgradPlan pl = wgrad_plan(d, x, dy);

@@ -578,7 +578,8 @@ def test_thin16_kernel_fwd_dgrad_and_fused_stats(case, mode):
         wmix = master.double().unsqueeze(0).expand(B, cout, cin, k, k, k)
         bias = torch.randn((cout,), generator=g)
     xr = x.clone().requires_grad_(True)
-    yr = torch.cat([F.conv3d(xr[i:i + 1], wmix[i], (bias[i] if per_sample else bias).double(), padding=1) for i in range(B)], 0)
+    wr = wmix.clone().requires_grad_(True)
+    yr = torch.cat([F.conv3d(xr[i:i + 1], wr[i], (bias[i] if per_sample else bias).double(), padding=1) for i in range(B)], 0)
     gy = torch.randn(yr.shape, generator=g).bfloat16().double()
     yr.backward(gy)
 
@@ -613,6 +614,13 @@ def test_thin16_kernel_fwd_dgrad_and_fused_stats(case, mode):
         dx, _, _ = ops._conv_bwd(xi, wk_d, dyi, k, 1, 0, per_sample, 2, None, True, False, 0, None)
         assert cout > 16 or lib.coma_last_kernel().decode().startswith("conv_thin16_k"), lib.coma_last_kernel()
         assert torch.isfinite(dx.float()).all() and rel(to_ext(dx), xr.grad) < 5e-3
+        # weight gradient on the voxels-along-K 16x16x32 kernel (transposed LDS reads): kernel layout [Bw, taps, cout, cin], fp32
+        _, dwk, _ = ops._conv_bwd(xi, wk_d, dyi, k, 1, 0, per_sample, 2, tuple(wk_f.shape), False, True, 0, None)
+        assert lib.coma_last_kernel().decode().startswith("conv_thin16_wgrad_k"), lib.coma_last_kernel()
+        gw = wr.grad.reshape(B, cout, cin, 27).permute(0, 3, 1, 2)
+        if not per_sample:
+            gw = gw.sum(0, keepdim=True)
+        assert torch.isfinite(dwk).all() and rel(dwk, gw) < 2e-5, rel(dwk, gw)      # bf16-exact operands, fp32 accumulation
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
