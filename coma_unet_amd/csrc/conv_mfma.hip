@@ -3011,6 +3011,167 @@ static int conv_thin16_wgrad(const coma_conv_desc* d, const coma_tensor* x, cons
   return 0;
 }
 
+// =====================================================================================
+// conv_f32_wgrad16_k -- fp32 weight gradient of the >= 32-channel stride-1 3x3x3 layers (W >= 32) in the voxels-along-K
+// form of conv_thin16f_wgrad_k: a block owns a 32 (n) x 32 (c) weight tile pair and walks 2x4x32-voxel tiles; wave w keeps
+// the 27 taps of ONE 16 x 16 sub-tile (n half = w & 1, c half = w >> 1: 108 accumulator registers) and runs all 256
+// voxels of the tile through them, 4 voxels per v_mfma_f32_16x16x4_f32, both operands one 4-byte LDS read per lane
+// (dense dy tile [256][32], x halo [816][32]: 136 KB, one block per CU).  The next tile's 34 staging pieces per thread
+// are fetched into registers in one burst right after the LDS image is complete (3-4 % of a tile's 55 k MFMA cycles).
+// =====================================================================================
+struct F32W16P {
+  const float* x; int ldx; long sbx; int D, H, W, C;
+  const float* dy; int ldn; long sbn; int N;
+  unsigned xbytes, dbytes;
+  int ntx, nty, ntz, ids_total, ids_per_block, cblocks;
+  float* dwk; long wsb;
+};
+
+__global__ __launch_bounds__(256, 1) void conv_f32_wgrad16_k(F32W16P p) {
+  constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ, TM = TX * TY * TZ;
+  constexpr int CB = 32;                               // channels per block on either side
+  constexpr int HIT = (HV * 8 + 255) / 256, DIT = TM * 8 / 256, NIT = HIT + DIT;      // 16-byte pieces per thread: 26 + 8
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Hl = reinterpret_cast<float*>(smem);          // [HV][32]
+  float* Dl = Hl + HV * CB;                            // [TM][32]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z;
+  const int n0 = (blockIdx.y / p.cblocks) * CB, c0 = (blockIdx.y % p.cblocks) * CB;
+  const int lv = lane & 15, lg = lane >> 4;
+  const float* xb = p.x + (long)b * p.sbx + c0;
+  const float* db = p.dy + (long)b * p.sbn + n0;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, p.dbytes, 0x00020000);
+  constexpr unsigned OOB = 0x7fff0000u;
+
+  // staging: piece = tid + 256 it -> (row = piece >> 3, 4-channel chunk = piece & 7 = tid & 7)
+  const unsigned choff = (unsigned)((tid & 7) * 16);
+  int s_pos[NIT];                                      // packed (z + 1) | (y + 1) << 4 | (x + 1) << 8
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (it < HIT) {
+      const int row = (tid + 256 * it) >> 3;
+      const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+      s_pos[it] = row < HV ? (hz | (hy << 4) | (hx << 8)) : (15 | (15 << 4) | (255 << 8));
+    } else {
+      const int row = (tid + 256 * (it - HIT)) >> 3;
+      s_pos[it] = ((row >> 7) + 1) | ((((row >> 5) & 3) + 1) << 4) | (((row & 31) + 1) << 8);
+    }
+  }
+  uint4 sreg[NIT];
+  auto issue_all = [&](int z0, int y0, int x0, const __amdgpu_buffer_rsrc_t& rx, const __amdgpu_buffer_rsrc_t& rd) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int gz = z0 - 1 + (s_pos[it] & 15), gy = y0 - 1 + ((s_pos[it] >> 4) & 15), gx = x0 - 1 + (s_pos[it] >> 8);
+      const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      const unsigned off = (unsigned)(((gz * p.H + gy) * p.W + gx) * (it < HIT ? p.ldx : p.ldn)) * 4u + choff;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(it < HIT ? rx : rd, ok ? off : OOB, 0, 0);
+      sreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (it < HIT) { if (((tid + 256 * it) >> 3) < HV) reinterpret_cast<uint4*>(Hl)[tid + 256 * it] = sreg[it]; }
+      else reinterpret_cast<uint4*>(Dl)[tid + 256 * (it - HIT)] = sreg[it];
+    }
+  };
+
+  const int nh = wid & 1, ch = wid >> 1;               // this wave's 16 x 16 sub-tile
+  const int dbase = lg * CB + 16 * nh + lv;            // + voxel row * CB
+  const int xbase = lg * CB + 16 * ch + lv;            // + halo row * CB + tap offset
+  f32x4_t acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int id_begin = xcd_remap(blockIdx.x, gridDim.x) * p.ids_per_block;
+  int id_end = id_begin + p.ids_per_block;
+  if (id_end > p.ids_total) id_end = p.ids_total;
+  int id = id_begin, tix = 0, tiy = 0, tiz = 0;
+  while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
+  if (id < id_end) issue_all(tiz * TZ, tiy * TY, tix * TX, rs_x, rs_d);
+  while (id < id_end) {
+    int nid = id + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nid < id_end && !tile_coords(nid, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nid;
+    const bool has_next = nid < id_end;
+    const __amdgpu_buffer_rsrc_t rn_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, has_next ? p.xbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, has_next ? p.dbytes : 0, 0x00020000);
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    issue_all(ntiz * TZ, ntiy * TY, ntix * TX, rn_x, rn_d);
+    // 8 (z, y) rows of 32 voxels = 8 K steps each; fragments one step ahead
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+      const int drow = r * 32 * CB, xrow = (((r >> 2) * HY + (r & 3)) * HX) * CB;
+      float af[2], bf[2][27];
+      auto rd = [&](int s_, int buf) __attribute__((always_inline)) {
+        af[buf] = Dl[dbase + drow + 4 * s_ * CB];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) bf[buf][t] = Hl[xbase + xrow + 4 * s_ * CB + (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * CB];
+      };
+      rd(0, 0);
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        if (s_ + 1 < 8) rd(s_ + 1, (s_ + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s_ & 1], bf[s_ & 1][t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
+  }
+  // ---- merge: every wave owns its outputs within the block: fp32 atomics straight into dwk[tap][n][c] ----
+  float* wout = p.dwk + (long)b * p.wsb;
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 16 * nh + 4 * lg + j, c = c0 + 16 * ch + lv;
+      atomicAdd(wout + ((long)t * p.N + n) * p.C + c, acc[t][j]);
+    }
+}
+
+static bool f32_wgrad16_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  static const bool on = []{ const char* e = getenv("COMA_F32W16"); return !(e && e[0] == '0'); }();
+  return on && d->form == 0 && d->ksize == 3 && d->stride == 1 && x->dtype == COMA_F32 && dy->dtype == COMA_F32 && x->W >= 32 &&
+         x->C % 32 == 0 && dy->C % 32 == 0 && x->ld % 4 == 0 && x->sb % 4 == 0 && dy->ld % 4 == 0 && dy->sb % 4 == 0 &&
+         (!x->data || aligned16(x->data)) && (!dy->data || aligned16(dy->data)) &&
+         (unsigned long long)t_vox(x) * x->ld * 4 < 0x7fff0000ull && (unsigned long long)t_vox(dy) * dy->ld * 4 < 0x7fff0000ull;
+}
+
+static int conv_f32_wgrad16(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s) {
+  F32W16P q;
+  q.x = (const float*)x->data; q.ldx = (int)x->ld; q.sbx = x->sb; q.D = x->D; q.H = x->H; q.W = x->W; q.C = x->C;
+  q.dy = (const float*)dy->data; q.ldn = (int)dy->ld; q.sbn = dy->sb; q.N = dy->C;
+  // (descriptor ranges are measured from the block's channel offset: a piece past the tensor's end of another block's
+  //  slice is still inside this allocation except for the last rows -- the voxel bounds test excludes those)
+  q.xbytes = (unsigned)((unsigned long long)t_vox(x) * x->ld * 4);
+  q.dbytes = (unsigned)((unsigned long long)t_vox(dy) * dy->ld * 4);
+  q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
+  q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
+  q.cblocks = q.C / 32;
+  const int pairs = q.cblocks * (q.N / 32);
+  int gx = 256 / (pairs * x->B);
+  if (gx < 1) gx = 1;
+  if (gx > q.ids_total) gx = q.ids_total;
+  q.ids_per_block = (q.ids_total + gx - 1) / gx;
+  gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
+  const long wsz1 = 27L * q.N * q.C, wsz = wsz1 * (d->per_sample_w ? x->B : 1);
+  q.wsb = d->per_sample_w ? wsz1 : 0;
+  q.dwk = dwk;
+  if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  const size_t lds = (size_t)(34 * 6 * 4 + 256) * 32 * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)conv_f32_wgrad16_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  coma_set_kernel_tag("conv_f32_wgrad16_k");
+  hipLaunchKernelGGL(conv_f32_wgrad16_k, dim3((unsigned)gx, (unsigned)pairs, (unsigned)x->B), dim3(256), lds, s, q);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
 static bool thin16f_wgrad_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   static const bool on = []{ const char* e = getenv("COMA_THIN16F"); return !(e && e[0] == '0'); }();
   const int nmax = x->C <= 4 ? 32 : 16;
@@ -3222,6 +3383,7 @@ int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_te
   if (thin16_wgrad_ok(d, x, dy)) return conv_thin16_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
   if (wgrad2_ok(d, x, dy)) return conv_mfma_wgrad2(d, x, dy, dwk, ws, ws_bytes, s);
   if (thin16f_wgrad_ok(d, x, dy)) return conv_thin16f_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
+  if (f32_wgrad16_ok(d, x, dy)) return conv_f32_wgrad16(d, x, dy, dwk, s);
   WgradPlan pl = wgrad_plan(d, x, dy);
   COMA_CHECK(pl.ok, "conv_mfma_wgrad: unsupported problem");
   pl.p.dwk = dwk;
