@@ -3020,53 +3020,61 @@ static int conv_thin16_wgrad(const coma_conv_desc* d, const coma_tensor* x, cons
 // are fetched into registers in one burst right after the LDS image is complete (3-4 % of a tile's 55 k MFMA cycles).
 // =====================================================================================
 struct F32W16P {
-  const float* x; int ldx; long sbx; int D, H, W, C;
-  const float* dy; int ldn; long sbn; int N;
-  unsigned xbytes, dbytes;
+  const float* dn; int ldd; long sbd; int Mz, My, Mx;      // dense operand (FORM 0: dy, FORM 1: x) on the coarse grid
+  const float* ga; int ldg; long sbg; int Gz, Gy, Gx;      // gathered operand (FORM 0: x, FORM 1: dy)
+  int N, C;
+  unsigned dbytes, gbytes;
   int ntx, nty, ntz, ids_total, ids_per_block, cblocks;
   float* dwk; long wsb;
 };
 
+// S = stride (1 or 2), FORM = 0 forward convolution (dense dy, gathered x) / 1 transposed stride-2 convolution (dense x,
+// gathered dy).  S = 2: a 1 x 2 x 32 dense tile (64 voxels) with its 3 x 5 x 65 gathered region (125 KB of LDS).
+template <int S, int FORM>
 __global__ __launch_bounds__(256, 1) void conv_f32_wgrad16_k(F32W16P p) {
-  constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ, TM = TX * TY * TZ;
+  constexpr int TX = 32, TY = S == 1 ? 4 : 2, TZ = S == 1 ? 2 : 1, TM = TX * TY * TZ;
+  constexpr int HX = (TX - 1) * S + 3, HY = (TY - 1) * S + 3, HZ = (TZ - 1) * S + 3, HV = HX * HY * HZ;
   constexpr int CB = 32;                               // channels per block on either side
-  constexpr int HIT = (HV * 8 + 255) / 256, DIT = TM * 8 / 256, NIT = HIT + DIT;      // 16-byte pieces per thread: 26 + 8
+  constexpr int HIT = (HV * 8 + 255) / 256, DIT = TM * 8 / 256, NIT = HIT + DIT;      // 16-byte pieces per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Hl = reinterpret_cast<float*>(smem);          // [HV][32]
-  float* Dl = Hl + HV * CB;                            // [TM][32]
+  float* Hl = reinterpret_cast<float*>(smem);          // [HV][32] gathered
+  float* Dl = Hl + HV * CB;                            // [TM][32] dense
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z;
   const int n0 = (blockIdx.y / p.cblocks) * CB, c0 = (blockIdx.y % p.cblocks) * CB;
   const int lv = lane & 15, lg = lane >> 4;
-  const float* xb = p.x + (long)b * p.sbx + c0;
-  const float* db = p.dy + (long)b * p.sbn + n0;
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, p.xbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, p.dbytes, 0x00020000);
+  const float* dnb = p.dn + (long)b * p.sbd + (FORM == 0 ? n0 : c0);
+  const float* gab = p.ga + (long)b * p.sbg + (FORM == 0 ? c0 : n0);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gab), 0, p.gbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dnb), 0, p.dbytes, 0x00020000);
   constexpr unsigned OOB = 0x7fff0000u;
 
-  // staging: piece = tid + 256 it -> (row = piece >> 3, 4-channel chunk = piece & 7 = tid & 7)
+  // staging: piece = tid + 256 it -> (row = piece >> 3, 4-channel chunk = tid & 7); positions relative to the tile origin + 1
   const unsigned choff = (unsigned)((tid & 7) * 16);
-  int s_pos[NIT];                                      // packed (z + 1) | (y + 1) << 4 | (x + 1) << 8
+  int s_pos[NIT];                                      // packed z | y << 4 | x << 8
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     if (it < HIT) {
       const int row = (tid + 256 * it) >> 3;
       const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
-      s_pos[it] = row < HV ? (hz | (hy << 4) | (hx << 8)) : (15 | (15 << 4) | (255 << 8));
+      s_pos[it] = row < HV ? (hz | (hy << 4) | (hx << 8)) : (15 | (15 << 4) | (1023 << 8));
     } else {
       const int row = (tid + 256 * (it - HIT)) >> 3;
-      s_pos[it] = ((row >> 7) + 1) | ((((row >> 5) & 3) + 1) << 4) | (((row & 31) + 1) << 8);
+      s_pos[it] = ((row / (TY * 32)) + 1) | ((((row >> 5) % TY) + 1) << 4) | (((row & 31) + 1) << 8);
     }
   }
   uint4 sreg[NIT];
-  auto issue_all = [&](int z0, int y0, int x0, const __amdgpu_buffer_rsrc_t& rx, const __amdgpu_buffer_rsrc_t& rd) __attribute__((always_inline)) {
+  auto issue_all = [&](int z0, int y0, int x0, const __amdgpu_buffer_rsrc_t& rg, const __amdgpu_buffer_rsrc_t& rd) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int gz = z0 - 1 + (s_pos[it] & 15), gy = y0 - 1 + ((s_pos[it] >> 4) & 15), gx = x0 - 1 + (s_pos[it] >> 8);
-      const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      const unsigned off = (unsigned)(((gz * p.H + gy) * p.W + gx) * (it < HIT ? p.ldx : p.ldn)) * 4u + choff;
-      const auto v = __builtin_amdgcn_raw_buffer_load_b128(it < HIT ? rx : rd, ok ? off : OOB, 0, 0);
+      const int sc = it < HIT ? S : 1;
+      const int gz = sc * z0 - 1 + (s_pos[it] & 15), gy = sc * y0 - 1 + ((s_pos[it] >> 4) & 15), gx = sc * x0 - 1 + (s_pos[it] >> 8);
+      const bool ok = it < HIT ? ((unsigned)gz < (unsigned)p.Gz && (unsigned)gy < (unsigned)p.Gy && (unsigned)gx < (unsigned)p.Gx)
+                               : ((unsigned)gz < (unsigned)p.Mz && (unsigned)gy < (unsigned)p.My && (unsigned)gx < (unsigned)p.Mx);
+      const unsigned off = it < HIT ? (unsigned)(((gz * p.Gy + gy) * p.Gx + gx) * p.ldg) * 4u + choff
+                                    : (unsigned)(((gz * p.My + gy) * p.Mx + gx) * p.ldd) * 4u + choff;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(it < HIT ? rg : rd, ok ? off : OOB, 0, 0);
       sreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
     }
   };
@@ -3078,9 +3086,10 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad16_k(F32W16P p) {
     }
   };
 
-  const int nh = wid & 1, ch = wid >> 1;               // this wave's 16 x 16 sub-tile
-  const int dbase = lg * CB + 16 * nh + lv;            // + voxel row * CB
-  const int xbase = lg * CB + 16 * ch + lv;            // + halo row * CB + tap offset
+  const int nh = wid & 1, ch = wid >> 1;               // this wave's 16 x 16 sub-tile (n half, c half)
+  // rows of the MFMA = output channels n (operand A), columns = input channels c (operand B)
+  const int dbase = lg * CB + 16 * (FORM == 0 ? nh : ch) + lv;            // dense:    + voxel row * CB
+  const int gbase = S * lg * CB + 16 * (FORM == 0 ? ch : nh) + lv;        // gathered: + region row * CB + tap offset
   f32x4_t acc[27];
 #pragma unroll
   for (int t = 0; t < 27; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -3090,26 +3099,26 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad16_k(F32W16P p) {
   if (id_end > p.ids_total) id_end = p.ids_total;
   int id = id_begin, tix = 0, tiy = 0, tiz = 0;
   while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
-  if (id < id_end) issue_all(tiz * TZ, tiy * TY, tix * TX, rs_x, rs_d);
+  if (id < id_end) issue_all(tiz * TZ, tiy * TY, tix * TX, rs_g, rs_d);
   while (id < id_end) {
     int nid = id + 1, ntix = 0, ntiy = 0, ntiz = 0;
     while (nid < id_end && !tile_coords(nid, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nid;
     const bool has_next = nid < id_end;
-    const __amdgpu_buffer_rsrc_t rn_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, has_next ? p.xbytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rn_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, has_next ? p.dbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gab), 0, has_next ? p.gbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dnb), 0, has_next ? p.dbytes : 0, 0x00020000);
     __syncthreads();
     store_tile();
     __syncthreads();
-    issue_all(ntiz * TZ, ntiy * TY, ntix * TX, rn_x, rn_d);
-    // 8 (z, y) rows of 32 voxels = 8 K steps each; fragments one step ahead
+    issue_all(ntiz * TZ, ntiy * TY, ntix * TX, rn_g, rn_d);
+    // TZ * TY rows of 32 dense voxels = 8 K steps each; fragments one step ahead
 #pragma unroll 1
-    for (int r = 0; r < 8; ++r) {
-      const int drow = r * 32 * CB, xrow = (((r >> 2) * HY + (r & 3)) * HX) * CB;
-      float af[2], bf[2][27];
+    for (int r = 0; r < TZ * TY; ++r) {
+      const int drow = r * 32 * CB, grow = ((((r / TY) * S) * HY + (r % TY) * S) * HX) * CB;
+      float df[2], gf[2][27];
       auto rd = [&](int s_, int buf) __attribute__((always_inline)) {
-        af[buf] = Dl[dbase + drow + 4 * s_ * CB];
+        df[buf] = Dl[dbase + drow + 4 * s_ * CB];
 #pragma unroll
-        for (int t = 0; t < 27; ++t) bf[buf][t] = Hl[xbase + xrow + 4 * s_ * CB + (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * CB];
+        for (int t = 0; t < 27; ++t) gf[buf][t] = Hl[gbase + grow + S * 4 * s_ * CB + (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * CB];
       };
       rd(0, 0);
 #pragma unroll
@@ -3117,7 +3126,9 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad16_k(F32W16P p) {
         if (s_ + 1 < 8) rd(s_ + 1, (s_ + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 27; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s_ & 1], bf[s_ & 1][t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 27; ++t)
+          acc[t] = FORM == 0 ? __builtin_amdgcn_mfma_f32_16x16x4f32(df[s_ & 1], gf[s_ & 1][t], acc[t], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x4f32(gf[s_ & 1][t], df[s_ & 1], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -3136,21 +3147,26 @@ __global__ __launch_bounds__(256, 1) void conv_f32_wgrad16_k(F32W16P p) {
 
 static bool f32_wgrad16_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   static const bool on = []{ const char* e = getenv("COMA_F32W16"); return !(e && e[0] == '0'); }();
-  return on && d->form == 0 && d->ksize == 3 && d->stride == 1 && x->dtype == COMA_F32 && dy->dtype == COMA_F32 && x->W >= 32 &&
+  const coma_tensor* dn = d->form == 0 ? dy : x;        // dense (coarse) operand
+  const bool shape = d->ksize == 3 && ((d->form == 0 && (d->stride == 1 || d->stride == 2)) || (d->form == 1 && d->stride == 2));
+  return on && shape && x->dtype == COMA_F32 && dy->dtype == COMA_F32 && dn->W >= 32 &&
          x->C % 32 == 0 && dy->C % 32 == 0 && x->ld % 4 == 0 && x->sb % 4 == 0 && dy->ld % 4 == 0 && dy->sb % 4 == 0 &&
          (!x->data || aligned16(x->data)) && (!dy->data || aligned16(dy->data)) &&
          (unsigned long long)t_vox(x) * x->ld * 4 < 0x7fff0000ull && (unsigned long long)t_vox(dy) * dy->ld * 4 < 0x7fff0000ull;
 }
 
 static int conv_f32_wgrad16(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s) {
+  const coma_tensor* dn = d->form == 0 ? dy : x;
+  const coma_tensor* ga = d->form == 0 ? x : dy;
   F32W16P q;
-  q.x = (const float*)x->data; q.ldx = (int)x->ld; q.sbx = x->sb; q.D = x->D; q.H = x->H; q.W = x->W; q.C = x->C;
-  q.dy = (const float*)dy->data; q.ldn = (int)dy->ld; q.sbn = dy->sb; q.N = dy->C;
-  // (descriptor ranges are measured from the block's channel offset: a piece past the tensor's end of another block's
-  //  slice is still inside this allocation except for the last rows -- the voxel bounds test excludes those)
-  q.xbytes = (unsigned)((unsigned long long)t_vox(x) * x->ld * 4);
-  q.dbytes = (unsigned)((unsigned long long)t_vox(dy) * dy->ld * 4);
-  q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
+  q.dn = (const float*)dn->data; q.ldd = (int)dn->ld; q.sbd = dn->sb; q.Mz = dn->D; q.My = dn->H; q.Mx = dn->W;
+  q.ga = (const float*)ga->data; q.ldg = (int)ga->ld; q.sbg = ga->sb; q.Gz = ga->D; q.Gy = ga->H; q.Gx = ga->W;
+  q.N = dy->C; q.C = x->C;
+  // (descriptor ranges are measured from the block's channel offset; the voxel bounds test keeps every piece inside)
+  q.dbytes = (unsigned)((unsigned long long)t_vox(dn) * dn->ld * 4);
+  q.gbytes = (unsigned)((unsigned long long)t_vox(ga) * ga->ld * 4);
+  const int S = d->stride, tz = S == 1 ? 2 : 1, ty = S == 1 ? 4 : 2;
+  q.ntx = (q.Mx + 31) / 32; q.nty = (q.My + ty - 1) / ty; q.ntz = (q.Mz + tz - 1) / tz;
   q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
   q.cblocks = q.C / 32;
   const int pairs = q.cblocks * (q.N / 32);
@@ -3163,11 +3179,19 @@ static int conv_f32_wgrad16(const coma_conv_desc* d, const coma_tensor* x, const
   q.wsb = d->per_sample_w ? wsz1 : 0;
   q.dwk = dwk;
   if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
-  const size_t lds = (size_t)(34 * 6 * 4 + 256) * 32 * 4;
+  const size_t lds = S == 1 ? (size_t)(34 * 6 * 4 + 256) * 32 * 4 : (size_t)(65 * 5 * 3 + 64) * 32 * 4;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)conv_f32_wgrad16_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  coma_set_kernel_tag("conv_f32_wgrad16_k");
-  hipLaunchKernelGGL(conv_f32_wgrad16_k, dim3((unsigned)gx, (unsigned)pairs, (unsigned)x->B), dim3(256), lds, s, q);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_f32_wgrad16_k<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_f32_wgrad16_k<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_f32_wgrad16_k<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const dim3 grid((unsigned)gx, (unsigned)pairs, (unsigned)x->B);
+  coma_set_kernel_tag("conv_f32_wgrad16_k<%d, %d>", S, d->form);
+  if (S == 1) hipLaunchKernelGGL((conv_f32_wgrad16_k<1, 0>), grid, dim3(256), lds, s, q);
+  else if (d->form == 0) hipLaunchKernelGGL((conv_f32_wgrad16_k<2, 0>), grid, dim3(256), lds, s, q);
+  else hipLaunchKernelGGL((conv_f32_wgrad16_k<2, 1>), grid, dim3(256), lds, s, q);
   COMA_LAUNCH_CHECK();
   return 0;
 }
