@@ -3196,6 +3196,205 @@ static int conv_f32_wgrad16(const coma_conv_desc* d, const coma_tensor* x, const
   return 0;
 }
 
+// =====================================================================================
+// conv_bf16_wgrad16_k -- bf16 weight gradient of >= 32-channel 3x3x3 layers with a coarse width >= 32 (stride 2 and
+// transposed: the layers the gather-style conv_mfma_wgrad_k ran at 150-200 TFLOP/s), voxels along K on
+// v_mfma_f32_16x16x32_bf16 as in conv_thin16_wgrad_k / conv_f32_wgrad16_k: a block owns a 32 x 32 weight tile pair, wave w
+// the 27 taps of one 16 x 16 sub-tile (108 accumulator registers), one dense row of 32 voxels per MFMA.  Both operands sit
+// voxel-major in LDS as two 16-channel planes with 32-byte rows (so that the 8 rows a 32-lane half reads transposed are
+// conflict-free) and are fetched with ds_read_b64_tr_b16; a stride-2 gathered operand just doubles the row step in the
+// lanes' addresses.  The whole (row, tap) sequence of a tile is unrolled; gathered fragments run RING MFMAs ahead.
+// =====================================================================================
+struct B16W16P {
+  const bf16_t* dn; int ldd; long sbd; int Mz, My, Mx;
+  const bf16_t* ga; int ldg; long sbg; int Gz, Gy, Gx;
+  int N, C;
+  unsigned dbytes, gbytes;
+  int ntx, nty, ntz, ids_total, ids_per_block, cblocks;
+  float* dwk; long wsb;
+};
+
+template <int S, int FORM>
+__global__ __launch_bounds__(256, 2) void conv_bf16_wgrad16_k(B16W16P p) {
+  constexpr int TX = 32, TY = S == 1 ? 4 : 2, TZ = S == 1 ? 2 : 1, TM = TX * TY * TZ, NR = TY * TZ;
+  constexpr int HX = (TX - 1) * S + 3, HY = (TY - 1) * S + 3, HZ = (TZ - 1) * S + 3, HV = HX * HY * HZ;
+  constexpr int HIT = (HV * 4 + 255) / 256, DIT = (TM * 4 + 255) / 256, NIT = HIT + DIT;      // 16-byte pieces per thread
+  constexpr int GPL = HV * 32, DPL = TM * 32;           // bytes per 16-channel plane
+  constexpr int RING = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Hl = smem;                                      // gathered: [2 planes][HV][16 ch]
+  char* Dl = smem + 2 * GPL;                            // dense:    [2 planes][TM][16 ch]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z;
+  const int n0 = (blockIdx.y / p.cblocks) * 32, c0 = (blockIdx.y % p.cblocks) * 32;
+  const int lv = lane & 15, lg = lane >> 4;
+  const bf16_t* dnb = p.dn + (long)b * p.sbd + (FORM == 0 ? n0 : c0);
+  const bf16_t* gab = p.ga + (long)b * p.sbg + (FORM == 0 ? c0 : n0);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(gab), 0, p.gbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dnb), 0, p.dbytes, 0x00020000);
+  constexpr unsigned OOB = 0x7fff0000u;
+
+  // staging: piece = tid + 256 it -> (row = piece >> 2, 8-channel chunk = tid & 3); LDS slot: plane chunk >> 1, half chunk & 1
+  const unsigned choff = (unsigned)((tid & 3) * 16);
+  const int lds_ch = ((tid & 3) >> 1), lds_hf = (tid & 1) * 16;
+  int s_pos[NIT];                                      // packed z | y << 4 | x << 8 (relative to the tile origin - 1)
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (it < HIT) {
+      const int row = (tid + 256 * it) >> 2;
+      const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+      s_pos[it] = row < HV ? (hz | (hy << 4) | (hx << 8)) : (15 | (15 << 4) | (1023 << 8));
+    } else {
+      const int row = (tid + 256 * (it - HIT)) >> 2;
+      s_pos[it] = row < TM ? (((row / (TY * 32)) + 1) | ((((row >> 5) % TY) + 1) << 4) | (((row & 31) + 1) << 8)) : (15 | (15 << 4) | (1023 << 8));
+    }
+  }
+  uint4 sreg[NIT];
+  auto issue = [&](int it, int z0, int y0, int x0, const __amdgpu_buffer_rsrc_t& rg, const __amdgpu_buffer_rsrc_t& rd) __attribute__((always_inline)) {
+    const int sc = it < HIT ? S : 1;
+    const int gz = sc * z0 - 1 + (s_pos[it] & 15), gy = sc * y0 - 1 + ((s_pos[it] >> 4) & 15), gx = sc * x0 - 1 + (s_pos[it] >> 8);
+    const bool ok = it < HIT ? ((unsigned)gz < (unsigned)p.Gz && (unsigned)gy < (unsigned)p.Gy && (unsigned)gx < (unsigned)p.Gx)
+                             : ((unsigned)gz < (unsigned)p.Mz && (unsigned)gy < (unsigned)p.My && (unsigned)gx < (unsigned)p.Mx);
+    const unsigned off = it < HIT ? (unsigned)(((gz * p.Gy + gy) * p.Gx + gx) * p.ldg) * 2u + choff
+                                  : (unsigned)(((gz * p.My + gy) * p.Mx + gx) * p.ldd) * 2u + choff;
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(it < HIT ? rg : rd, ok ? off : OOB, 0, 0);
+    sreg[it] = make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (it < HIT) {
+        const int row = (tid + 256 * it) >> 2;
+        if (row < HV) *reinterpret_cast<uint4*>(Hl + lds_ch * GPL + row * 32 + lds_hf) = sreg[it];
+      } else {
+        const int row = (tid + 256 * (it - HIT)) >> 2;
+        if (row < TM) *reinterpret_cast<uint4*>(Dl + lds_ch * DPL + row * 32 + lds_hf) = sreg[it];
+      }
+    }
+  };
+
+  const int nh = wid & 1, ch = wid >> 1;               // this wave's 16 x 16 sub-tile (n half, c half)
+  // transposed-read addresses: lane 4q+p of group lg supplies voxel x = 4 lg + q (second read: + 16), columns 4p..4p+3
+  const int q4 = lv >> 2, p4 = lv & 3;
+  const int vx = 4 * lg + q4;
+  const int d_addr = (FORM == 0 ? nh : ch) * DPL + vx * 32 + 8 * p4;              // + dense row r * 32 * 32
+  const int g_addr = (FORM == 0 ? ch : nh) * GPL + S * vx * 32 + 8 * p4;          // + gathered row offset + tap offset
+  f32x4_t acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int id_begin = xcd_remap(blockIdx.x, gridDim.x) * p.ids_per_block;
+  int id_end = id_begin + p.ids_per_block;
+  if (id_end > p.ids_total) id_end = p.ids_total;
+  int id = id_begin, tix = 0, tiy = 0, tiz = 0;
+  while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
+  if (id < id_end) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) issue(it, tiz * TZ, tiy * TY, tix * TX, rs_g, rs_d);
+  }
+  while (id < id_end) {
+    int nid = id + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nid < id_end && !tile_coords(nid, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nid;
+    const bool has_next = nid < id_end;
+    const __amdgpu_buffer_rsrc_t rn_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(gab), 0, has_next ? p.gbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dnb), 0, has_next ? p.dbytes : 0, 0x00020000);
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    constexpr int NPAIR = NR * 27;
+    auto rdg = [&](int pi) __attribute__((always_inline)) -> bf16x8_t {
+      const int r = pi / 27, t = pi % 27;
+      const int off = ((((r / TY) * S + t / 9) * HY + (r % TY) * S + (t / 3) % 3) * HX + t % 3) * 32;
+      const char* src = Hl + g_addr + off;
+      const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src));
+      const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src + S * 16 * 32));
+      return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto rdd = [&](int r) __attribute__((always_inline)) -> bf16x8_t {
+      const char* src = Dl + d_addr + r * 32 * 32;
+      const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src));
+      const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src + 16 * 32));
+      return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    bf16x8_t dfr[2], gring[RING];
+    dfr[0] = rdd(0);
+#pragma unroll
+    for (int pi = 0; pi < RING; ++pi) gring[pi] = rdg(pi);
+#pragma unroll
+    for (int pi = 0; pi < NPAIR; ++pi) {
+      const int r = pi / 27, t = pi % 27;
+      const bf16x8_t gcur = gring[pi % RING];
+      if (pi + RING < NPAIR) gring[pi % RING] = rdg(pi + RING);
+      if (t == 0 && r + 1 < NR) dfr[(r + 1) & 1] = rdd(r + 1);
+      if (pi < NIT) issue(pi, ntiz * TZ, ntiy * TY, ntix * TX, rn_g, rn_d);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[t] = FORM == 0 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[r & 1], gcur, acc[t], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(gcur, dfr[r & 1], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(NIT <= NPAIR, "one staging piece per MFMA");
+    id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
+  }
+  float* wout = p.dwk + (long)b * p.wsb;
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 16 * nh + 4 * lg + j, c = c0 + 16 * ch + lv;
+      atomicAdd(wout + ((long)t * p.N + n) * p.C + c, acc[t][j]);
+    }
+}
+
+static bool bf16_wgrad16_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  // (stride 1 stays on conv_mfma_wgrad2_k: a 256-voxel tile would be 216 unrolled (row, tap) pairs here)
+  static const bool on = []{ const char* e = getenv("COMA_B16W16"); return !(e && e[0] == '0'); }();
+  const coma_tensor* dn = d->form == 0 ? dy : x;
+  const bool shape = d->ksize == 3 && d->stride == 2 && (d->form == 0 || d->form == 1);
+  return on && shape && x->dtype == COMA_BF16 && dy->dtype == COMA_BF16 && dn->W >= 32 &&
+         x->C % 32 == 0 && dy->C % 32 == 0 && x->ld % 8 == 0 && x->sb % 8 == 0 && dy->ld % 8 == 0 && dy->sb % 8 == 0 &&
+         (!x->data || aligned16(x->data)) && (!dy->data || aligned16(dy->data)) &&
+         (unsigned long long)t_vox(x) * x->ld * 2 < 0x7fff0000ull && (unsigned long long)t_vox(dy) * dy->ld * 2 < 0x7fff0000ull;
+}
+
+static int conv_bf16_wgrad16(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s) {
+  const coma_tensor* dn = d->form == 0 ? dy : x;
+  const coma_tensor* ga = d->form == 0 ? x : dy;
+  B16W16P q;
+  q.dn = (const bf16_t*)dn->data; q.ldd = (int)dn->ld; q.sbd = dn->sb; q.Mz = dn->D; q.My = dn->H; q.Mx = dn->W;
+  q.ga = (const bf16_t*)ga->data; q.ldg = (int)ga->ld; q.sbg = ga->sb; q.Gz = ga->D; q.Gy = ga->H; q.Gx = ga->W;
+  q.N = dy->C; q.C = x->C;
+  q.dbytes = (unsigned)((unsigned long long)t_vox(dn) * dn->ld * 2);
+  q.gbytes = (unsigned)((unsigned long long)t_vox(ga) * ga->ld * 2);
+  const int S = d->stride, tz = S == 1 ? 2 : 1, ty = S == 1 ? 4 : 2;
+  q.ntx = (q.Mx + 31) / 32; q.nty = (q.My + ty - 1) / ty; q.ntz = (q.Mz + tz - 1) / tz;
+  q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
+  q.cblocks = q.C / 32;
+  const int pairs = q.cblocks * (q.N / 32);
+  int gx = 512 / (pairs * x->B);
+  if (gx < 1) gx = 1;
+  if (gx > q.ids_total) gx = q.ids_total;
+  q.ids_per_block = (q.ids_total + gx - 1) / gx;
+  gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
+  const long wsz1 = 27L * q.N * q.C, wsz = wsz1 * (d->per_sample_w ? x->B : 1);
+  q.wsb = d->per_sample_w ? wsz1 : 0;
+  q.dwk = dwk;
+  if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  const size_t lds = S == 1 ? (size_t)(34 * 6 * 4 + 256) * 64 : (size_t)(65 * 5 * 3 + 64) * 64;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_bf16_wgrad16_k<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_wgrad16_k<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr = true;
+  }
+  const dim3 grid((unsigned)gx, (unsigned)pairs, (unsigned)x->B);
+  coma_set_kernel_tag("conv_bf16_wgrad16_k<%d, %d>", S, d->form);
+  if (d->form == 0) hipLaunchKernelGGL((conv_bf16_wgrad16_k<2, 0>), grid, dim3(256), lds, s, q);
+  else hipLaunchKernelGGL((conv_bf16_wgrad16_k<2, 1>), grid, dim3(256), lds, s, q);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
 static bool thin16f_wgrad_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   static const bool on = []{ const char* e = getenv("COMA_THIN16F"); return !(e && e[0] == '0'); }();
   const int nmax = x->C <= 4 ? 32 : 16;
@@ -3405,6 +3604,7 @@ size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, c
 int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws, size_t ws_bytes,
                     hipStream_t s) {
   if (thin16_wgrad_ok(d, x, dy)) return conv_thin16_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
+  if (bf16_wgrad16_ok(d, x, dy)) return conv_bf16_wgrad16(d, x, dy, dwk, s);
   if (wgrad2_ok(d, x, dy)) return conv_mfma_wgrad2(d, x, dy, dwk, ws, ws_bytes, s);
   if (thin16f_wgrad_ok(d, x, dy)) return conv_thin16f_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
   if (f32_wgrad16_ok(d, x, dy)) return conv_f32_wgrad16(d, x, dy, dwk, s);

@@ -353,6 +353,8 @@ MFMA_CASES = [
     (96, 64, 3, 1, False, (3, 5, 40)), (32, 96, 3, 1, False, (35, 4, 32)),
     # deep layers: split-K forward / data-gradient, single-producer (plain-store) weight-gradient tiles
     (512, 384, 3, 1, False, (4, 4, 8)), (256, 512, 3, 2, False, (4, 6, 8)), (512, 256, 3, 2, True, (2, 3, 4)),
+    # voxels-along-K weight gradients (conv_bf16_wgrad16_k / conv_f32_wgrad16_k): stride 2 and transposed, coarse width >= 32
+    (32, 64, 3, 2, False, (6, 8, 66)), (64, 32, 3, 2, True, (3, 4, 33)), (64, 64, 3, 2, False, (5, 6, 70)),
 ]
 
 
@@ -413,8 +415,6 @@ F32_MFMA_CASES = MFMA_CASES + [
     # fp32 mode also takes 16-channel inputs and 16-channel outputs on the halo kernels (16 channels = one 64-byte row)
     (16, 16, 3, 1, False, (6, 5, 40)), (16, 32, 3, 1, False, (5, 9, 17)), (48, 16, 3, 1, False, (4, 6, 33)),
     (16, 32, 3, 2, False, (8, 10, 12)), (64, 64, 3, 1, False, (9, 12, 64)), (128, 64, 3, 1, False, (3, 8, 8)),
-    # voxels-along-K fp32 weight gradient (conv_f32_wgrad16_k): stride 2 and transposed with a coarse width >= 32
-    (32, 64, 3, 2, False, (6, 8, 66)), (64, 32, 3, 2, True, (3, 4, 33)), (64, 64, 3, 2, False, (5, 6, 70)),
 ]
 
 
