@@ -3214,13 +3214,13 @@ struct B16W16P {
   float* dwk; long wsb;
 };
 
-template <int S, int FORM>
-__global__ __launch_bounds__(256, 2) void conv_bf16_wgrad16_k(B16W16P p) {
+template <int S, int FORM>      // (108 accumulators + 36 ring + 68 staged-piece registers: one block per CU)
+__global__ __launch_bounds__(256, 1) void conv_bf16_wgrad16_k(B16W16P p) {
   constexpr int TX = 32, TY = S == 1 ? 4 : 2, TZ = S == 1 ? 2 : 1, TM = TX * TY * TZ, NR = TY * TZ;
   constexpr int HX = (TX - 1) * S + 3, HY = (TY - 1) * S + 3, HZ = (TZ - 1) * S + 3, HV = HX * HY * HZ;
   constexpr int HIT = (HV * 4 + 255) / 256, DIT = (TM * 4 + 255) / 256, NIT = HIT + DIT;      // 16-byte pieces per thread
   constexpr int GPL = HV * 32, DPL = TM * 32;           // bytes per 16-channel plane
-  constexpr int RING = 4;
+  constexpr int RING = 9;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Hl = smem;                                      // gathered: [2 planes][HV][16 ch]
   char* Dl = smem + 2 * GPL;                            // dense:    [2 planes][TM][16 ch]
@@ -3302,11 +3302,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad16_k(B16W16P p) {
     __syncthreads();
     store_tile();
     __syncthreads();
-    constexpr int NPAIR = NR * 27;
-    auto rdg = [&](int pi) __attribute__((always_inline)) -> bf16x8_t {
-      const int r = pi / 27, t = pi % 27;
-      const int off = ((((r / TY) * S + t / 9) * HY + (r % TY) * S + (t / 3) % 3) * HX + t % 3) * 32;
-      const char* src = Hl + g_addr + off;
+    // One dense row (32 voxels) = one K step = 27 MFMAs (unrolled); the rows are a run-time loop.  Gathered fragments run
+    // RING MFMAs ahead, across the row boundary (RING divides 27: the ring slot of a tap is a compile-time constant); the
+    // next tile's staging pieces are issued under the first row (peeled), one per MFMA.
+    auto rdg = [&](int goff, int t) __attribute__((always_inline)) -> bf16x8_t {
+      const char* src = Hl + g_addr + goff + (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * 32;
       const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src));
       const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src + S * 16 * 32));
       return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -3317,23 +3317,32 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad16_k(B16W16P p) {
       const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(src + 16 * 32));
       return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
-    bf16x8_t dfr[2], gring[RING];
-    dfr[0] = rdd(0);
+    auto growoff = [&](int r) __attribute__((always_inline)) { return ((((r / TY) * S) * HY + (r % TY) * S) * HX) * 32; };
+    bf16x8_t dcur = rdd(0), gring[RING];
 #pragma unroll
-    for (int pi = 0; pi < RING; ++pi) gring[pi] = rdg(pi);
-#pragma unroll
-    for (int pi = 0; pi < NPAIR; ++pi) {
-      const int r = pi / 27, t = pi % 27;
-      const bf16x8_t gcur = gring[pi % RING];
-      if (pi + RING < NPAIR) gring[pi % RING] = rdg(pi + RING);
-      if (t == 0 && r + 1 < NR) dfr[(r + 1) & 1] = rdd(r + 1);
-      if (pi < NIT) issue(pi, ntiz * TZ, ntiy * TY, ntix * TX, rn_g, rn_d);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[t] = FORM == 0 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[r & 1], gcur, acc[t], 0, 0, 0)
-                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(gcur, dfr[r & 1], acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < RING; ++i) gring[i] = rdg(0, i);
+#define COMA_W16_ROW(R_, FIRST_)                                                                                          \
+    {                                                                                                                     \
+      const int r_ = (R_), rn_ = r_ + 1 < NR ? r_ + 1 : r_;                                                               \
+      const int goff_r = growoff(r_), goff_n = growoff(rn_);                                                              \
+      bf16x8_t dnext = dcur;                                                                                              \
+      _Pragma("unroll") for (int t = 0; t < 27; ++t) {                                                                    \
+        const bf16x8_t gcur = gring[t % RING];                                                                            \
+        gring[t % RING] = t + RING < 27 ? rdg(goff_r, t + RING) : rdg(goff_n, t + RING - 27);                             \
+        if (t == 0) dnext = rdd(rn_);                                                                                     \
+        if (FIRST_ && t < NIT) issue(t, ntiz * TZ, ntiy * TY, ntix * TX, rn_g, rn_d);                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        acc[t] = FORM == 0 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(dcur, gcur, acc[t], 0, 0, 0)                         \
+                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(gcur, dcur, acc[t], 0, 0, 0);                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+      }                                                                                                                   \
+      dcur = dnext;                                                                                                       \
     }
-    static_assert(NIT <= NPAIR, "one staging piece per MFMA");
+    static_assert(NIT <= 27 && 27 % RING == 0, "staging pieces under the first row; ring slots compile-time");
+    COMA_W16_ROW(0, true)
+#pragma unroll 1
+    for (int r = 1; r < NR; ++r) COMA_W16_ROW(r, false)
+#undef COMA_W16_ROW
     id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
   }
   float* wout = p.dwk + (long)b * p.wsb;
@@ -3347,11 +3356,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad16_k(B16W16P p) {
 }
 
 static bool bf16_wgrad16_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
-  // (stride 1 stays on conv_mfma_wgrad2_k: a 256-voxel tile would be 216 unrolled (row, tap) pairs here)
-  static const bool on = []{ const char* e = getenv("COMA_B16W16"); return !(e && e[0] == '0'); }();
+  static const int mode = []{ const char* e = getenv("COMA_B16W16"); return e ? atoi(e) : 1; }();   // 0 off, 1 stride-2 / transposed, 2 also stride 1
   const coma_tensor* dn = d->form == 0 ? dy : x;
-  const bool shape = d->ksize == 3 && d->stride == 2 && (d->form == 0 || d->form == 1);
-  return on && shape && x->dtype == COMA_BF16 && dy->dtype == COMA_BF16 && dn->W >= 32 &&
+  const bool shape = d->ksize == 3 && ((d->stride == 2 && (d->form == 0 || d->form == 1)) || (mode >= 2 && d->form == 0 && d->stride == 1));
+  return mode > 0 && shape && x->dtype == COMA_BF16 && dy->dtype == COMA_BF16 && dn->W >= 32 &&
          x->C % 32 == 0 && dy->C % 32 == 0 && x->ld % 8 == 0 && x->sb % 8 == 0 && dy->ld % 8 == 0 && dy->sb % 8 == 0 &&
          (!x->data || aligned16(x->data)) && (!dy->data || aligned16(dy->data)) &&
          (unsigned long long)t_vox(x) * x->ld * 2 < 0x7fff0000ull && (unsigned long long)t_vox(dy) * dy->ld * 2 < 0x7fff0000ull;
@@ -3371,7 +3379,7 @@ static int conv_bf16_wgrad16(const coma_conv_desc* d, const coma_tensor* x, cons
   q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
   q.cblocks = q.C / 32;
   const int pairs = q.cblocks * (q.N / 32);
-  int gx = 512 / (pairs * x->B);
+  int gx = 256 / (pairs * x->B);
   if (gx < 1) gx = 1;
   if (gx > q.ids_total) gx = q.ids_total;
   q.ids_per_block = (q.ids_total + gx - 1) / gx;
@@ -3383,13 +3391,15 @@ static int conv_bf16_wgrad16(const coma_conv_desc* d, const coma_tensor* x, cons
   const size_t lds = S == 1 ? (size_t)(34 * 6 * 4 + 256) * 64 : (size_t)(65 * 5 * 3 + 64) * 64;
   static bool attr = false;
   if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_bf16_wgrad16_k<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_bf16_wgrad16_k<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_bf16_wgrad16_k<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr = true;
   }
   const dim3 grid((unsigned)gx, (unsigned)pairs, (unsigned)x->B);
   coma_set_kernel_tag("conv_bf16_wgrad16_k<%d, %d>", S, d->form);
-  if (d->form == 0) hipLaunchKernelGGL((conv_bf16_wgrad16_k<2, 0>), grid, dim3(256), lds, s, q);
+  if (S == 1) hipLaunchKernelGGL((conv_bf16_wgrad16_k<1, 0>), grid, dim3(256), lds, s, q);
+  else if (d->form == 0) hipLaunchKernelGGL((conv_bf16_wgrad16_k<2, 0>), grid, dim3(256), lds, s, q);
   else hipLaunchKernelGGL((conv_bf16_wgrad16_k<2, 1>), grid, dim3(256), lds, s, q);
   COMA_LAUNCH_CHECK();
   return 0;
