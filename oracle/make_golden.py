@@ -7,10 +7,14 @@ ORACLE / TEST INFRASTRUCTURE.  Two kinds of fixture:
    ``data_util`` and ``VolumeDataset`` are put in ``sys.modules`` first; the
    file uses them only in code paths that are not exercised, criterions.py:138,
    401,671).  Pins RnCLoss / LabelDifference / FeatureSimilarity /
-   GenerativeContrastiveLoss of ``criterions_oracle.py``.  The reference's
-   RoiMSE cannot run on CPU tensors, so the reference's
-   GenerativeContrastiveLoss is driven with the oracle's RoiMSE as its
-   ``gen_loss`` member: that pins the combination logic, not RoiMSE itself.
+   GenerativeContrastiveLoss of ``criterions_oracle.py`` AND RoiMSE
+   (criterions.py:181-211): the reference's ``RoiMSE.forward`` allocates its
+   mask with ``device=roi.get_device()`` which is -1 for a plain CPU tensor
+   (SURVEY F11); handing it ``roi`` as a ``torch.Tensor`` subclass whose
+   ``get_device()`` answers "cpu" lets the UNMODIFIED reference code run on the
+   CPU.  ``roimse{B}_*`` hold its loss vector and ``pred.grad`` for B = 1, 2, 3
+   with the 225/100/7.5 weight mix, and the reference's
+   GenerativeContrastiveLoss is driven with the reference's own RoiMSE.
 2. ``model32_oracle.npz`` -- outputs of THIS REPO'S oracle model at 32^3
    (BASELINE config C1) from seeded weights and seeded synthetic inputs.  The
    reference model cannot be imported (MONAI / CondConv absent): this fixture
@@ -38,6 +42,14 @@ def import_reference_criterions():
     import criterions as ref  # noqa: the reference's own file, this container only
     sys.path.pop(0)
     return ref
+
+
+class CpuRoi(torch.Tensor):
+    """A CPU tensor that answers ``get_device()`` with "cpu" (a plain one answers -1, which the reference's
+    ``torch.zeros(..., device=roi.get_device())`` at criterions.py:182 rejects)."""
+
+    def get_device(self):
+        return "cpu"
 
 
 def golden_criterions():
@@ -71,13 +83,26 @@ def golden_criterions():
     w = torch.full((36,), 225.0)
     w[3] = 100.0
     w[20] = 7.5
-    gen = orc.RoiMSE(w, ROI_INDICES, voxel_wise=False)
-    gen.batch_reduction = None
+    gen = ref.RoiMSE(w, ROI_INDICES, voxel_wise=False)        # the REFERENCE's class (validation.py:146)
+    gen.batch_reduction = None                                 # attn_unet_data_parallel.py:717
     crit = ref.GenerativeContrastiveLoss(ref.RnCLoss(), gen, torch.nn.TripletMarginLoss(1), 0.0, 1.0)
     feats = torch.relu(torch.randn((B, 512), generator=g))
     labels = torch.rand((B, 6), generator=g)
     fin = torch.relu(torch.randn((B, 1, 1, 1, 2048), generator=g))
-    tot, genl, ps, ds = crit(pred, gt, roi, (fin, torch.zeros_like(fin), torch.zeros_like(fin)), (feats, labels))
+    tot, genl, ps, ds = crit(pred, gt, roi.as_subclass(CpuRoi), (fin, torch.zeros_like(fin), torch.zeros_like(fin)),
+                             (feats, labels))
+    # RoiMSE on its own: loss vector + d(sum loss)/d pred for B = 1, 2, 3 (what train_dp back-propagates, criterions.py:560)
+    for Bn in (1, 2, 3):
+        p_ = torch.rand((Bn, 1, S, S, S), generator=g).requires_grad_(True)
+        g_ = torch.rand((Bn, 1, S, S, S), generator=g)
+        r_ = lab[torch.randint(0, len(lab), (Bn, 1, S, S, S), generator=g)]
+        lv = gen(p_, g_, r_.as_subclass(CpuRoi))
+        torch.sum(lv).backward()
+        out.update({f"roimse{Bn}_pred": p_.detach().numpy(), f"roimse{Bn}_gt": g_.numpy(), f"roimse{Bn}_roi": r_.numpy(),
+                    f"roimse{Bn}_loss": lv.detach().numpy(), f"roimse{Bn}_grad": p_.grad.numpy()})
+    gen_mean = ref.RoiMSE(w, ROI_INDICES, voxel_wise=False)    # default batch_reduction="mean" (criterions.py:206-208)
+    out["roimse3_mean"] = np.asarray(float(gen_mean(torch.from_numpy(out["roimse3_pred"]), torch.from_numpy(out["roimse3_gt"]),
+                                                    torch.from_numpy(out["roimse3_roi"]).as_subclass(CpuRoi))))
     out.update(gcl_pred=pred.numpy(), gcl_gt=gt.numpy(), gcl_roi=roi.numpy(), gcl_w=w.numpy(),
                gcl_feats=feats.numpy(), gcl_labels=labels.numpy(), gcl_fin=fin.numpy(),
                gcl_total=np.asarray(float(tot)), gcl_gen=genl.detach().numpy(),

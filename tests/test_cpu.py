@@ -57,6 +57,20 @@ def test_oracle_losses_match_reference_golden():
             assert rel(feats.grad, g[f"rnc{ci}_grad"]) < 1e-5
     w = torch.from_numpy(g["gcl_w"])
     from oracle.coma_oracle import ROI_INDICES
+    # RoiMSE (criterions.py:181-211): loss vector, d(sum loss)/d pred and the "mean" reduction, produced by the REFERENCE's
+    # own class (roi handed over as a tensor subclass whose get_device() answers "cpu": oracle/make_golden.py)
+    for Bn in (1, 2, 3):
+        pred = torch.from_numpy(g[f"roimse{Bn}_pred"]).requires_grad_(True)
+        gen = orc.RoiMSE(w, ROI_INDICES)
+        gen.batch_reduction = None
+        lv = gen(pred, torch.from_numpy(g[f"roimse{Bn}_gt"]), torch.from_numpy(g[f"roimse{Bn}_roi"]))
+        assert tuple(lv.shape) == tuple(g[f"roimse{Bn}_loss"].shape) == (Bn, 1)
+        assert rel(lv, g[f"roimse{Bn}_loss"]) < 1e-6
+        torch.sum(lv).backward()
+        assert rel(pred.grad, g[f"roimse{Bn}_grad"]) < 1e-6
+    gen = orc.RoiMSE(w, ROI_INDICES)      # default reduction "mean"
+    lm = gen(torch.from_numpy(g["roimse3_pred"]), torch.from_numpy(g["roimse3_gt"]), torch.from_numpy(g["roimse3_roi"]))
+    assert abs(float(lm) - float(g["roimse3_mean"])) < 1e-6 * abs(float(g["roimse3_mean"]))
     gen = orc.RoiMSE(w, ROI_INDICES)
     gen.batch_reduction = None
     crit = orc.GenerativeContrastiveLoss(orc.RnCLoss(), gen, torch.nn.TripletMarginLoss(1), 0.0, 1.0)

@@ -200,6 +200,39 @@ def test_gate_pieces(C, dtype):
     assert rel(to_ext(pi.grad), pr.grad) < tol * 3
 
 
+def test_roimse_matches_reference_golden():
+    """The fused RoiMSE kernels against tests/golden/criterions_ref.npz `roimse{B}_*`: loss vectors and pred gradients
+    computed by the REFERENCE's own criterions.RoiMSE.forward (criterions.py:181-211; oracle/make_golden.py), fp32,
+    225/100/7.5 weight mix, B = 1, 2, 3; and the module-level `RoiMSE` of coma_unet_amd.criterions with both reductions."""
+    import os
+    import numpy as np
+    ops, L = _ops()
+    from coma_unet_amd.roi_tables import ROI_INDICES
+    from coma_unet_amd import criterions as prod
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "criterions_ref.npz"))
+    dev = "cuda"
+    ids = torch.tensor(ROI_INDICES, dtype=torch.int32, device=dev)
+    w = torch.from_numpy(g["gcl_w"])
+    for Bn in (1, 2, 3):
+        pg = to_int(torch.from_numpy(g[f"roimse{Bn}_pred"])).to(dev).requires_grad_(True)
+        lg = ops.RoiMSELoss.apply(pg, to_int(torch.from_numpy(g[f"roimse{Bn}_gt"])).to(dev),
+                                  to_int(torch.from_numpy(g[f"roimse{Bn}_roi"])).to(dev), ids, w.to(dev))
+        assert tuple(lg.shape) == (Bn, 1)
+        assert rel(lg, torch.from_numpy(g[f"roimse{Bn}_loss"])) < 1e-5
+        lg.sum().backward()
+        assert rel(to_ext(pg.grad), torch.from_numpy(g[f"roimse{Bn}_grad"])) < 1e-5
+        crit = prod.RoiMSE(w.to(dev), ROI_INDICES, reduction=None)
+        pe = torch.from_numpy(g[f"roimse{Bn}_pred"]).to(dev).requires_grad_(True)
+        lv = crit(pe, torch.from_numpy(g[f"roimse{Bn}_gt"]).to(dev), torch.from_numpy(g[f"roimse{Bn}_roi"]).to(dev))
+        assert rel(lv, torch.from_numpy(g[f"roimse{Bn}_loss"])) < 1e-5
+        lv.sum().backward()
+        assert rel(pe.grad, torch.from_numpy(g[f"roimse{Bn}_grad"])) < 1e-5
+    crit = prod.RoiMSE(w.to(dev), ROI_INDICES)      # reduction "mean" (criterions.py:206-208)
+    lm = crit(torch.from_numpy(g["roimse3_pred"]).to(dev), torch.from_numpy(g["roimse3_gt"]).to(dev),
+              torch.from_numpy(g["roimse3_roi"]).to(dev))
+    assert abs(float(lm) - float(g["roimse3_mean"])) < 1e-5 * abs(float(g["roimse3_mean"]))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_roi_paint_and_losses(dtype):
     ops, L = _ops()
