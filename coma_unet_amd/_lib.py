@@ -99,7 +99,7 @@ def _load():
         if fn is None:
             raise ImportError(f"libcoma_unet.so does not export {name}")
         fn.restype, fn.argtypes = res, args
-    if lib.coma_abi_version() != 1:
+    if lib.coma_abi_version() != 2:
         raise ImportError("libcoma_unet.so ABI version mismatch")
     return lib
 

@@ -21,12 +21,16 @@ def checkpoint_dict(epoch, model, optimizer, loss, scheduler=None):
     return ckpt
 
 
-def save_checkpoint(save_path, epoch, model, optimizer, loss, scheduler=None, checkpoint_iter=None):
+def save_checkpoint(save_path, epoch, model, optimizer, loss, scheduler=None, checkpoint_iter=None, write=True):
     """<save_path>/checkpoints/checkpoint_latest_epoch.pth every call and checkpoint_epoch_<n>.pth every
-    ``checkpoint_iter`` epochs (:953-955).  Returns the list of files written."""
+    ``checkpoint_iter`` epochs (:953-955).  Returns the list of files written.  ``write=False`` (data-parallel ranks other
+    than 0): the state is still assembled -- ``FusedAdamW.state_dict()`` is a collective under a sharded gradient exchange
+    -- but nothing is written."""
+    ckpt = checkpoint_dict(epoch, model, optimizer, loss, scheduler)
+    if not write:
+        return []
     d = os.path.join(save_path, "checkpoints")
     os.makedirs(d, exist_ok=True)
-    ckpt = checkpoint_dict(epoch, model, optimizer, loss, scheduler)
     files = [os.path.join(d, "checkpoint_latest_epoch.pth")]
     if checkpoint_iter and epoch % checkpoint_iter == 0:
         files.append(os.path.join(d, f"checkpoint_epoch_{epoch}.pth"))

@@ -9,6 +9,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <string.h>
+#include <mutex>
+#include <string>
 
 namespace {
 struct Rccl {
@@ -22,13 +24,19 @@ struct Rccl {
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
+  std::string why;        // dlerror() text of the failed load, read ONCE (dlerror() clears itself)
 };
 
+void rccl_load(Rccl& r);
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+// one load per process, safe against the RCCL watchdog / capture threads calling in concurrently
 Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r.ok ? &r : nullptr;
-  tried = true;
+  std::call_once(g_rccl_once, [] { rccl_load(g_rccl); });
+  return g_rccl.ok ? &g_rccl : nullptr;
+}
+void rccl_load(Rccl& r) {
   const char* names[] = {"librccl.so.1", "librccl.so"};
   for (int pass = 0; pass < 2 && !r.h; ++pass)          // pass 0: an instance the process already holds (PyTorch's)
     for (const char* n : names) {
@@ -36,14 +44,14 @@ Rccl* rccl() {
       if (r.h) break;
     }
   if (!r.h) r.h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!r.h) return nullptr;
+  if (!r.h) { const char* e = dlerror(); r.why = e ? e : "dlopen failed"; return; }
 #define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.h, name))
   SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
   SYM(AllReduce, "ncclAllReduce"); SYM(ReduceScatter, "ncclReduceScatter"); SYM(AllGather, "ncclAllGather");
   SYM(Broadcast, "ncclBroadcast"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.ReduceScatter && r.AllGather && r.Broadcast;
-  return r.ok ? &r : nullptr;
+  if (!r.ok) r.why = "a required ncclXxx symbol is missing";
 }
 
 int fail(Rccl* r, ncclResult_t e, const char* what) {
@@ -54,7 +62,7 @@ int fail(Rccl* r, ncclResult_t e, const char* what) {
 
 #define RCCL_OR_FAIL()                                                              \
   Rccl* r = rccl();                                                                 \
-  if (!r) { coma_set_error("librccl could not be loaded (dlopen): %s", dlerror() ? dlerror() : "symbols missing"); return 4; }
+  if (!r) { coma_set_error("librccl could not be loaded (dlopen): %s", g_rccl.why.c_str()); return 4; }
 
 extern "C" int coma_comm_unique_id(void* id_out) {
   RCCL_OR_FAIL();

@@ -260,6 +260,8 @@ class StreamedGradExchange:
         self._launched = None
         self._forked = False
         self.early = 0                # buckets of the last step that went out before backward had finished
+        if sharded:
+            optimizer.shard_exchange = self      # FusedAdamW.state_dict() gathers the sharded moments through gather_state()
 
     # -- layout ---------------------------------------------------------------------------------------------------
     def _build(self):
@@ -368,6 +370,28 @@ class StreamedGradExchange:
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         return True      # the optimizer step has been taken
+
+
+    def gather_state(self):
+        """Sharded mode: all-gather exp_avg / exp_avg_sq so that every rank holds the full AdamW state (rank r only ever
+        updates sub-slice r of every bucket; the reference's checkpoint, attn_unet_data_parallel.py:946-952, stores the
+        whole optimizer state).  Collective: called by FusedAdamW.state_dict() on every rank."""
+        if not self.sharded or self.world == 1:
+            return
+        if self._buckets is None:
+            if not self.opt.built:
+                return                 # nothing has been stepped in shards yet
+            self._build()
+        opt, side = self.opt, self.comm.side
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        for buf in (opt.flat_m, opt.flat_v):
+            for s0, e0 in self._buckets:
+                k = (e0 - s0) // self.world
+                b = buf[s0:e0]
+                self.comm.all_gather(b[self.comm.rank * k:(self.comm.rank + 1) * k], b, stream=side)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
 
 
 class _null:

@@ -125,17 +125,29 @@ class GradSink:
         SidePrep._live = 0
 
     @classmethod
-    def slot(cls, p):
-        # a new request proves that the kernels of every earlier request have been enqueued (python runs the backward
-        # nodes one after another on one stream): buckets those completed may go on the wire now
+    def slots(cls, params):
+        """Gradient slots of ALL the parameters ONE kernel launch is about to write (None where a parameter is not sunk).
+        Flushing and marking are separate steps: a new request proves that the kernels of every EARLIER request have been
+        enqueued (python runs the backward nodes one after another on one stream), so buckets those completed may go on the
+        wire now -- but the slots marked by THIS request only become sendable at the next request, after this node's kernel
+        has been launched.  (Asking slot by slot let the second request of a three-slot node -- Routing, NormAct -- flush a
+        bucket completed by the first one before the node's single kernel was enqueued: the collective read zeros.)"""
         if cls.listener is not None:
             cls.listener.flush_pending()
-        if p is None or not getattr(p, "_coma_sink", False) or p.grad is None or id(p) in cls.written:
-            return None
-        cls.written.add(id(p))
-        if cls.listener is not None:
-            cls.listener.mark(p)
-        return p.grad
+        out = []
+        for p in params:
+            if p is None or not getattr(p, "_coma_sink", False) or p.grad is None or id(p) in cls.written:
+                out.append(None)
+                continue
+            cls.written.add(id(p))
+            if cls.listener is not None:
+                cls.listener.mark(p)
+            out.append(p.grad)
+        return out
+
+    @classmethod
+    def slot(cls, p):
+        return cls.slots((p,))[0]
 
 
 class SidePrep:
@@ -318,7 +330,7 @@ class Routing(Function):
         B, NC = cov.shape
         E, N = r.shape[1], bias_e.shape[1]
         dev = cov.device
-        sinks = [GradSink.slot(p) for p in (Wr, br, be)]
+        sinks = GradSink.slots((Wr, br, be))      # one kernel writes all three: one flush, then three marks
         dWr = sinks[0] if sinks[0] is not None else _f32((E, NC), dev)
         dbr = sinks[1] if sinks[1] is not None else _f32((E,), dev)
         dbe = sinks[2] if sinks[2] is not None else _f32((E, N), dev)
@@ -563,7 +575,7 @@ class NormAct(Function):
         dev = x.device
         C = x.shape[4]
         dx = _new(x.shape, x.dtype, dev)
-        sinks = [GradSink.slot(p) for p in ctx.params]
+        sinks = GradSink.slots(ctx.params)      # one kernel chain writes all three: one flush, then three marks
         dgamma = sinks[0] if sinks[0] is not None else (_f32(C, dev) if gamma is not None else None)
         dbeta = sinks[1] if sinks[1] is not None else (_f32(C, dev) if beta is not None else None)
         dslope = sinks[2] if sinks[2] is not None else (_f32(1, dev) if slope is not None else None)

@@ -30,6 +30,9 @@ class FusedAdamW(torch.optim.Optimizer):
         # all-reduce from post-accumulate-grad hooks (those do not fire for sunk gradients).
         self.write_through = write_through
         self.pad_to = max(1, int(pad_to))   # flat buffers padded to a multiple of this (the world size, for sharded steps)
+        # set by data_parallel.StreamedGradExchange(sharded=True): each rank then steps only its own sub-slices of the moment
+        # buffers, and state_dict() must re-assemble them first (a COLLECTIVE: every rank calls state_dict())
+        self.shard_exchange = None
 
     # -- layout -------------------------------------------------------------------------
     def _build(self):
@@ -127,6 +130,11 @@ class FusedAdamW(torch.optim.Optimizer):
 
     # -- torch.optim.AdamW-compatible checkpoint format (attn_unet_data_parallel.py:946-952) ----
     def state_dict(self):
+        """torch.optim.AdamW's format.  Under a sharded exchange the moments of this rank's sub-slices are current and the
+        others stopped at the last unsharded step: they are all-gathered first (every rank must call state_dict(), like any
+        collective; afterwards every rank holds the full, identical state)."""
+        if self.shard_exchange is not None and self.built:
+            self.shard_exchange.gather_state()
         params = self.param_groups[0]["params"]
         state = {}
         for i, p in enumerate(params):

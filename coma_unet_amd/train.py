@@ -71,7 +71,10 @@ class GraphedTrainStep:
     passed as a (B,36,2) tensor, fixed shapes.  New data is copied into the static input buffers.
     """
 
-    def __init__(self, model, criterion, optimizer, batch, warmup=3, reducer=None):
+    def __init__(self, model, criterion, optimizer, batch, warmup=3, reducer=None, prewarmed=False):
+        """prewarmed: the caller has already taken >= 2 eager steps at these shapes with this optimizer (the flat layout
+        exists, the workspaces are sized): capture without any warm-up step, so that no optimizer step is taken here
+        (train_loop.train_dp, where every step must be a real one on real data)."""
         assert getattr(model, "static_prompts", False), "graph capture needs static_prompts=True"
         self.model, self.criterion, self.optimizer, self.reducer = model, criterion, optimizer, reducer
         self.batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -83,12 +86,15 @@ class GraphedTrainStep:
             reducer.overlap = False          # hooks do not fire under replay
             reducer.remove_hooks()
             optimizer.set_write_through(True)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(warmup, 2)):      # builds the flat optimizer layout, sizes workspaces
-                train_step(model, criterion, optimizer, self.batch, reducer)
-        torch.cuda.current_stream().wait_stream(side)
+        if prewarmed:
+            assert optimizer.built, "prewarmed capture needs the optimizer's flat layout (two eager steps first)"
+        else:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(warmup, 2)):      # builds the flat optimizer layout, sizes workspaces
+                    train_step(model, criterion, optimizer, self.batch, reducer)
+            torch.cuda.current_stream().wait_stream(side)
         from ._lib import pin_workspace
         self._ws = pin_workspace(self.batch["mri"].device)     # the graph bakes this buffer's address in: keep it alive and in place
         self._capture()

@@ -27,7 +27,7 @@ from torch.optim.lr_scheduler import ReduceLROnPlateau
 
 from . import metrics as M
 from .checkpoint import save_checkpoint
-from .train import make_optimizer, train_step
+from .train import make_optimizer, train_step, GraphedTrainStep
 
 
 def extract_id(path: str) -> str:
@@ -70,10 +70,36 @@ def _dev(t, device):
     return t.to(device) if torch.is_tensor(t) else t
 
 
+def _dist_info(reducer):
+    """(world, rank) of the data-parallel job this loop is part of (1, 0 without a reducer / process group)."""
+    import torch.distributed as dist
+    world = int(getattr(reducer, "world", 1)) if reducer is not None else 1
+    rank = dist.get_rank() if (world > 1 and dist.is_initialized()) else 0
+    return world, rank
+
+
+def _same_shapes(a, b):
+    return all((not torch.is_tensor(v)) or (k in b and torch.is_tensor(b[k]) and tuple(b[k].shape) == tuple(v.shape)
+                                             and b[k].dtype == v.dtype) for k, v in a.items())
+
+
 def train_dp(model, criterion, train_loader, validation_loader, epochs, lr, save_path="", cuda_id=0, pred_sample_file="",
              from_checkpoint=False, **kwargs):
     """attn_unet_data_parallel.py:696.  Returns the list of per-epoch average losses (the reference returns None; the
-    list is additional)."""
+    list is additional).
+
+    Build-side kwargs (none exists upstream; all optional):
+     * ``graph`` ("auto" | True | False): replay the step from a captured hipGraph (train.GraphedTrainStep -- the path
+       bench.py measures) when the model was built with ``static_prompts=True``: the first two batches run eagerly (they
+       build the optimizer's flat layout and size the workspaces), the step is captured on the third and every later
+       batch of the same shape is copied into the graph's static input buffers and replayed; batches of another shape
+       (a short last batch) run eagerly.  "auto" = True when the model allows it.
+     * ``reducer`` (data_parallel.GradReducer | StreamedGradExchange): one process per GPU.  The optimizer is the
+       reducer's (its flat layout is what the reducer buckets); the plateau scheduler sees the loss of the GLOBAL
+       batch (all-reduced sums), so every rank keeps the same learning rate; checkpoints, CSVs and validation are rank 0's
+       (``optimizer.state_dict()`` is still called by every rank: it is a collective under a sharded exchange).
+     * ``optimizer``: use this FusedAdamW instead of building one (``from_checkpoint=True`` requires it, as upstream)."""
+    import torch.distributed as dist
     cwd = os.getcwd()
     fold = kwargs.get("fold_id")
     base = f"{cwd}/training_folds/adni_a4_first_scan_combined_folds/tau_prediction_lookups"
@@ -87,15 +113,31 @@ def train_dp(model, criterion, train_loader, validation_loader, epochs, lr, save
     overfit_val_iter = 10
     checkpoint_iter = val_iter
     start_epoch = 0
+    reducer = kwargs.get("reducer")
+    world, rank = _dist_info(reducer)
     if from_checkpoint:                                                                                   # :729-733
         optimizer = kwargs["optimizer"]
         start_epoch = kwargs["start_epoch"]
         scheduler = kwargs["scheduler"] if kwargs.get("scheduler") is not None else \
             ReduceLROnPlateau(optimizer, "min", patience=5, factor=0.2)
     else:                                                                                                 # :736-737
-        optimizer = make_optimizer(model, lr)
+        if kwargs.get("optimizer") is not None:
+            optimizer = kwargs["optimizer"]
+        elif reducer is not None:
+            optimizer = reducer.opt           # the reducer buckets THIS optimizer's flat gradient buffer
+        else:
+            optimizer = make_optimizer(model, lr)
+        for g in optimizer.param_groups:
+            g["lr"] = lr
         scheduler = ReduceLROnPlateau(optimizer, "min", patience=5)
-    reducer = kwargs.get("reducer")
+    if reducer is not None:
+        assert reducer.opt is optimizer, "train_dp(reducer=...) must step the optimizer the reducer was built on"
+    use_graph = kwargs.get("graph", "auto")
+    if use_graph == "auto":
+        use_graph = bool(getattr(model, "static_prompts", False))
+    if use_graph:
+        assert getattr(model, "static_prompts", False), "train_dp(graph=True) needs a model built with static_prompts=True"
+    graphed, eager_done = None, 0
     epoch_avg_losses = []
     hist = {k: [] for k in ("mae", "rse", "rrmse", "ssim", "mape", "avg_corr", "roi_maes", "roi_mapes", "roi_wrrmses",
                             "roi_corrs", "roi_rses")}
@@ -115,7 +157,15 @@ def train_dp(model, criterion, train_loader, validation_loader, epochs, lr, save
             priors = [lookup[get_id(p)] for p in tau_path]                                                # :809-810
             batch = dict(mri=_dev(mri, device), tau=_dev(tau, device), roi=_dev(roi, device), covars=_dev(covars, device),
                          roi_pred_dicts=priors)
-            (loss, gen_loss, pred_contra, ds_contra), outs = train_step(model, criterion, optimizer, batch, reducer)   # :806-885
+            if use_graph:
+                batch["roi_pred_dicts"] = model._priors(priors, batch["mri"].shape[0], device)            # (B, 36, 2) table
+            if use_graph and graphed is None and eager_done >= 2 and optimizer.built:
+                graphed = GraphedTrainStep(model, criterion, optimizer, batch, reducer=reducer, prewarmed=True)
+            if graphed is not None and _same_shapes(graphed.batch, batch):
+                (loss, gen_loss, pred_contra, ds_contra), outs = graphed(batch)                           # load + replay
+            else:
+                (loss, gen_loss, pred_contra, ds_contra), outs = train_step(model, criterion, optimizer, batch, reducer)   # :806-885
+                eager_done += 1
             epoch_loss += loss.item()                                                                     # :892
             gl = gen_loss.detach().reshape(-1).tolist()                                                   # :901-910 (one host read, not B)
             ds = float(ds_contra)
@@ -130,16 +180,25 @@ def train_dp(model, criterion, train_loader, validation_loader, epochs, lr, save
                 elif a == 0:
                     epoch_neg += gl[b] + ds
                     n_neg += 1
+        if world > 1:
+            # the plateau scheduler must see the same number on every rank, or the replicas' learning rates drift apart:
+            # the loss of the GLOBAL batch (what the reference's single process would have accumulated)
+            tot = torch.tensor([epoch_loss, float(num_samples)], dtype=torch.float64,
+                               device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            epoch_loss, num_samples = float(tot[0]), int(tot[1])
         if num_samples == 0:
             continue
         scheduler.step(epoch_loss / num_samples)                                                          # :921
         epoch_avg_losses.append(epoch_loss / num_samples)
-        logging.info(f"epoch {epoch}: avg loss {epoch_loss / num_samples:.6f} (gen {epoch_gen / num_samples:.6f}, "
-                     f"pred-contra {epoch_pred / num_samples:.6f}, ds-contra {epoch_ds / num_samples:.6f}; "
-                     f"pos {epoch_pos / max(n_pos, 1):.6f}, neg {epoch_neg / max(n_neg, 1):.6f})")
+        if rank == 0:
+            logging.info(f"epoch {epoch}: avg loss {epoch_loss / num_samples:.6f} (gen {epoch_gen / num_samples:.6f}, "
+                         f"pred-contra {epoch_pred / num_samples:.6f}, ds-contra {epoch_ds / num_samples:.6f}; "
+                         f"pos {epoch_pos / max(n_pos, 1):.6f}, neg {epoch_neg / max(n_neg, 1):.6f})")
         if save_path:                                                                                     # :943-955
-            save_checkpoint(save_path, epoch, model, optimizer, loss, scheduler, checkpoint_iter=checkpoint_iter)
-        if epoch % val_iter == 0 and validation_loader is not None:                                      # :957-1017
+            # every rank assembles the dict (FusedAdamW.state_dict() all-gathers sharded moments), rank 0 writes it
+            save_checkpoint(save_path, epoch, model, optimizer, loss, scheduler, checkpoint_iter=checkpoint_iter, write=rank == 0)
+        if epoch % val_iter == 0 and validation_loader is not None and rank == 0:                         # :957-1017
             with torch.no_grad():
                 val_save = os.path.join(save_path, f"{epoch}_output_samples") if save_path else ""
                 if val_save:
@@ -159,16 +218,16 @@ def train_dp(model, criterion, train_loader, validation_loader, epochs, lr, save
             if float(np.nanmean(roi_corr)) > best_avg_corr:
                 best_avg_corr = float(np.nanmean(roi_corr))
                 logging.info(f"Highest ROI Averaged Correlations so far: Epoch {epoch}")
-            model.train(True)
-            model.set_training(True)
-        if epoch != 0 and epoch > 29 and epoch % overfit_val_iter == 0:                                   # :1019-1034
+        if epoch != 0 and epoch > 29 and epoch % overfit_val_iter == 0 and rank == 0:                     # :1019-1034
             with torch.no_grad():
                 res = contrastive_test(model, train_loader, criterion.gen_loss.roi_indices, criterion.gen_loss.roi_weights,
                                        save_path="", cuda_id=cuda_id, pred_sample_file=pred_sample_file,
                                        with_train_loader=not kwargs.get("with_test_loader", False), in_sample_test=True, **kwargs)
                 print_metrics(criterion, *res[0][:10])
-            model.train(True)
-            model.set_training(True)
+        model.train(True)
+        model.set_training(True)
+        if world > 1:
+            dist.barrier()          # ranks 1.. wait for rank 0's validation before the next epoch's first collective
     return epoch_avg_losses
 
 

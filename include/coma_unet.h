@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define COMA_ABI_VERSION 1
+/* 2 (round 3): coma_conv_pick_algo / coma_conv_wgrad_algo may answer 3 (fp32 MFMA), algo 0 routes fp32 tensors to the
+ * fp32 MFMA kernels and one-channel 1x1x1 layers to conv_point1 (fp32 kernel-layout weights) before the bf16 MFMA path;
+ * new exports coma_last_kernel, coma_comm_*, coma_allreduce/reduce_scatter/allgather/broadcast. */
+#define COMA_ABI_VERSION 2
 
 enum { COMA_F32 = 0, COMA_BF16 = 1 };
 

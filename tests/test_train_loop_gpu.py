@@ -117,3 +117,37 @@ def test_train_dp_trains_checkpoints_validates_and_resumes(tmp_path):
                       optimizer=opt2, scheduler=sch2, start_epoch=start, roi_vecs_dict=lookup)
     assert len(more) == 1 and np.isfinite(more[0]) and more[0] < losses[0]
     assert opt2._flat_step == 9
+
+
+def test_train_dp_graphed_loop_matches_eager_loop():
+    """train_dp(graph=...) on a static_prompts model: batches 1-2 eager, capture on batch 3, later batches copied into the
+    graph's static inputs and replayed (the path bench.py times).  Same per-epoch losses as the all-eager loop -- lr 1e-5
+    so that the comparison is not about Adam turning fp32-atomic merge order into sign noise (test_graphed_step_matches_
+    eager_steps documents that spread) -- and the same number of optimizer steps; a short last batch falls back to eager."""
+    import coma_unet_amd as cu
+    from coma_unet_amd import attn_unet_data_parallel as A
+    from coma_unet_amd import train as T
+    train, lookup = _loader(5, 2, [[1, 0], [0, 1], [1, 1], [0, 0], [1, 0]], seed0=120, triplet=True)
+    short, lk2 = _loader(1, 1, [[1]], seed0=140, triplet=True)          # B = 1: another shape
+    lookup.update(lk2)
+    runs = {}
+    for mode in (False, True):
+        m = _model(21, static_prompts=True, compute_dtype=torch.bfloat16)
+        m.train(True)
+        crit = cu.build_reference_criterion()
+        opt = T.make_optimizer(m, 1e-5)
+        captured = []
+        orig = T.GraphedTrainStep._capture
+        T.GraphedTrainStep._capture = lambda self, _o=orig: (captured.append(1), _o(self))[1]
+        try:
+            losses = A.train_dp(m, crit, train + short, None, 2, 1e-5, save_path="", cuda_id=0, roi_vecs_dict=lookup, fold_id=0,
+                                graph=mode, optimizer=opt)
+        finally:
+            T.GraphedTrainStep._capture = orig
+        runs[mode] = (losses, opt._flat_step, len(captured))
+    (le, se, ce), (lg, sg, cg) = runs[False], runs[True]
+    assert ce == 0 and cg == 1                       # one capture, no re-capture (the learning rate did not change)
+    assert se == sg == 12                            # 2 epochs x 6 batches, every one a real optimizer step
+    assert len(le) == len(lg) == 2
+    for a, b in zip(lg, le):
+        assert np.isfinite(a) and abs(a - b) <= 2e-2 * abs(b), (lg, le)
