@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COMA_UNET_LIB") or os.path.join(_HERE, "libcoma_unet.so")   # (override: diagnostic builds, profiles/stamps_halo2.py)
 
 F32, BF16 = 0, 1
+ZEROED_OUT, ZEROED_WS = 1, 2
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY, ACT_SIGMOID, ACT_PRELU_RELU = range(6)
 NORM_BATCH, NORM_INSTANCE = 0, 1
 
@@ -39,26 +40,28 @@ SIGNATURES = {
     "coma_last_kernel": (C.c_char_p, []),
     "coma_weight_prep": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
     "coma_weight_prep_pair": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
-    "coma_weight_prep_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "coma_weight_prep_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _vp]),
     "coma_routing_fwd": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "coma_routing_bwd": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "coma_conv_pick_algo": (_i32, [_DP, _TP, _TP]),
     "coma_conv_fwd": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _vp]),
     "coma_conv_fwd_ws_bytes": (_sz, [_DP, _TP, _TP]),
-    "coma_conv_fwd_ws": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _vp, _sz, _vp]),
-    "coma_conv_fwd_norm_stats": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _i32, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),
+    "coma_conv_fwd_ws": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _vp, _sz, _i32, _vp]),
+    "coma_conv_fwd_norm_stats": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _i32, _vp, _vp, _sz, _i32, _vp]),
     "coma_conv_wgrad_algo": (_i32, [_DP, _TP, _TP]),
     "coma_conv_wgrad_ws_bytes": (_sz, [_DP, _TP, _TP]),
-    "coma_conv_wgrad": (_i32, [_DP, _TP, _TP, _vp, _vp, _vp, _sz, _vp]),
+    "coma_conv_wgrad": (_i32, [_DP, _TP, _TP, _vp, _vp, _vp, _sz, _i32, _vp]),
     "coma_norm_ws_bytes": (_sz, [_TP]),
-    "coma_norm_stats": (_i32, [_TP, _i32, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),
-    "coma_norm_act_fwd": (_i32, [_TP, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _TP, _vp]),
-    "coma_norm_act_bwd": (_i32, [_TP, _TP, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _TP, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "coma_norm_stats": (_i32, [_TP, _i32, _vp, _vp]),
+    "coma_norm_act_fwd": (_i32, [_TP, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _TP, _vp]),
+    "coma_norm_act_bwd": (_i32, [_TP, _TP, _i32, _vp, _f32, _vp, _vp, _i32, _vp, _TP, _vp, _vp, _vp, _vp, _vp]),
     "coma_add_relu_fwd": (_i32, [_TP, _TP, _TP, _vp]),
     "coma_add_relu_bwd": (_i32, [_TP, _TP, _TP, _vp]),
     "coma_gate_mul_fwd": (_i32, [_TP, _TP, _TP, _vp]),
     "coma_gate_mul_bwd": (_i32, [_TP, _TP, _TP, _TP, _i32, _TP, _vp]),
     "coma_add": (_i32, [_TP, _TP, _TP, _vp]),
+    "coma_cast_copy": (_i32, [_TP, _TP, _vp]),
+    "coma_zero_ranges": (_i32, [_vp, _vp, _i32, _i64, _vp]),
     "coma_batch_sum": (_i32, [_TP, _TP, _vp]),
     "coma_spatial_mean": (_i32, [_TP, _vp, _vp, _sz, _vp]),
     "coma_roi_paint_fwd": (_i32, [_TP, _TP, _vp, _vp, _i32, _vp, _vp, _vp, _TP, _vp]),
@@ -99,7 +102,7 @@ def _load():
         if fn is None:
             raise ImportError(f"libcoma_unet.so does not export {name}")
         fn.restype, fn.argtypes = res, args
-    if lib.coma_abi_version() != 2:
+    if lib.coma_abi_version() != 3:
         raise ImportError("libcoma_unet.so ABI version mismatch")
     return lib
 

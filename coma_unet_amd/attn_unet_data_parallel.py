@@ -26,6 +26,7 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from . import ops
+from ._lib import lib, ct, check
 from .layers import (Config, Convolution, MonaiConvBlock, CondConvolution, CondConvBlock, norm_act, conv_plain,
                      conv_then_bn, reset_cov_cache, cov_rows)
 from .ops import Out
@@ -47,6 +48,14 @@ def _padded_input(x, dtype):
     """(B, C, D, H, W) external volume -> internal (B, D, H, W, C) in the compute dtype, pitch-padded (ops._new)."""
     v = to_internal(x)
     xi = ops._new(tuple(v.shape), dtype, x.device)
+    if v.dtype in (torch.float32, torch.bfloat16) and (v.shape[4] == 1 or v.stride(4) == 1) and not v.requires_grad:
+        try:
+            cv = ct(v)                 # (B, 1, D, H, W) contiguous IS channels-last with one channel
+        except AssertionError:
+            cv = None
+        if cv is not None:
+            check(lib.coma_cast_copy(cv, ct(xi), L.stream()), "coma_cast_copy")
+            return xi
     xi.copy_(v)
     return xi
 

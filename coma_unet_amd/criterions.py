@@ -162,6 +162,13 @@ class RnCLoss(nn.Module):
         if len(features.shape) == 2 * len(labels.shape):
             features = torch.cat([features[:, 0], features[:, 1]], dim=0)
             labels = labels.repeat(2, 1)
+        if features.shape[0] <= 2:
+            # n = 2 (the reference's batch size, run.sh:13): each row has ONE off-diagonal logit, which is its own only
+            # "negative", so every log-probability is log(e^l / e^l) = 0 and the loss and its gradient are identically zero
+            # (tests/golden/criterions_ref.npz rnc0/rnc5 hold the reference's 0.0 and zero gradient for n = 2, 1).
+            # Same value, same zero gradient into `features` (so the last projection head keeps receiving zeros and AdamW
+            # keeps decaying it, as upstream) -- without the ~30 tiny launches of the general form.
+            return (features * 0.0).sum()
         label_diffs = self.label_diff_fn(labels)
         logits = self.feature_sim_fn(features).div(self.t)
         logits_max, _ = torch.max(logits, dim=1, keepdim=True)
@@ -188,6 +195,22 @@ class RnCLoss(nn.Module):
         return loss
 
 
+class _ZeroWeighted(torch.autograd.Function):
+    """A loss term whose weight is exactly 0.0 (criterions.py:562 `regulatory_weight * triplet`, validation.py:154): value 0,
+    gradient zeros -- what `0.0 * term` gives for any finite term -- without evaluating the term (TripletMarginLoss on
+    (B,1,1,1,2048): ~35 tiny ATen launches forward + backward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.meta = (x.shape, x.dtype, x.device)
+        return torch.zeros((), dtype=torch.float32, device=x.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype, device = ctx.meta
+        return torch.zeros(shape, dtype=dtype, device=device)
+
+
 class GenerativeContrastiveLoss(nn.Module):
     """L = gen_weight * sum_b gen_b + reg_weight * pred_space + ds_reg_weight * ds  (criterions.py:544-575)."""
 
@@ -199,6 +222,7 @@ class GenerativeContrastiveLoss(nn.Module):
         self.reg_weight = regulatory_weight
         self.ds_reg_weight = ds_regulatory_weight
         self.gen_weight = 1.0
+        self.skip_zero_weighted = True      # False: always evaluate the 0.0-weighted term, as the reference does
 
     def get_pred_space_contra_loss(self, representations):
         return self.pred_space_contra_loss(*representations)
@@ -209,8 +233,11 @@ class GenerativeContrastiveLoss(nn.Module):
     def forward(self, prediction, target, roi, final_representations, intermediate_extractions):
         gen_loss = self.gen_loss(prediction, target, roi)
         reduced_gen_loss = torch.sum(gen_loss) if self.gen_loss.batch_reduction is None else gen_loss
-        pred_space = self.get_pred_space_contra_loss(tuple(r.float() for r in final_representations))
-        total_pred_space = self.reg_weight * pred_space
+        if self.reg_weight == 0.0 and self.skip_zero_weighted:
+            total_pred_space = _ZeroWeighted.apply(final_representations[0])      # == 0.0 * triplet(...) for any finite triplet
+        else:
+            pred_space = self.get_pred_space_contra_loss(tuple(r.float() for r in final_representations))
+            total_pred_space = self.reg_weight * pred_space
         ds = self.get_ds_contra_loss(intermediate_extractions)
         total_ds = self.ds_reg_weight * ds
         total = self.gen_weight * reduced_gen_loss + total_pred_space + total_ds

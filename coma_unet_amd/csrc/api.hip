@@ -28,12 +28,12 @@ extern "C" const char* coma_last_error(void) { return g_err; }
 int conv_check(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int conv_direct_fwd(const coma_conv_desc* d, const coma_tensor* x, const float* wk, const float* bias,
                     const coma_tensor* y, hipStream_t s);
-int conv_direct_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s);
+int conv_direct_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s, int zeroed);
 // conv_point1.hip
 bool conv_point1_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int conv_point1_fwd(const coma_conv_desc* d, const coma_tensor* x, const float* wk, const float* bias, const coma_tensor* y,
                     hipStream_t s);
-int conv_point1_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s);
+int conv_point1_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s, int zeroed);
 // norm.hip
 int colsum(const coma_tensor* x, int per_sample, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 // conv_mfma.hip
@@ -41,15 +41,12 @@ bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const co
 bool conv_f32mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                   const coma_tensor* y, hipStream_t s, double2* stats = nullptr, int stats_inst = 0,
-                  int* stats_chunks = nullptr, void* ws = nullptr, size_t ws_bytes = 0);
+                  int* stats_chunks = nullptr, void* ws = nullptr, size_t ws_bytes = 0, int ws_zeroed = 0);
 size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
-// norm.hip
-int norm_stats_finalize(const double2* partial, int nchunks, int G, int C, int64_t R, float eps, float* mean, float* rstd,
-                        float* running_mean, float* running_var, float momentum, hipStream_t s);
 bool conv_mfma_wgrad_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
 size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
 int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws,
-                    size_t ws_bytes, hipStream_t s);
+                    size_t ws_bytes, hipStream_t s, int zeroed);
 
 extern "C" int coma_conv_pick_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (d->algo == 1) return 1;
@@ -65,23 +62,25 @@ extern "C" size_t coma_conv_fwd_ws_bytes(const coma_conv_desc* d, const coma_ten
 
 extern "C" int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
                              const float* bias, const coma_tensor* y, void* stream) {
-  return coma_conv_fwd_ws(d, x, wk, wk_dtype, bias, y, nullptr, 0, stream);
+  return coma_conv_fwd_ws(d, x, wk, wk_dtype, bias, y, nullptr, 0, 0, stream);
 }
 
 extern "C" int coma_conv_fwd_ws(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
-                                const float* bias, const coma_tensor* y, void* ws, size_t ws_bytes, void* stream) {
+                                const float* bias, const coma_tensor* y, void* ws, size_t ws_bytes, int32_t zeroed,
+                                void* stream) {
   if (int rc = conv_check(d, x, y)) return rc;
   COMA_CHECK(wk, "conv_fwd: null weights");
+  const int wz = (zeroed & COMA_ZEROED_WS) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const int algo = coma_conv_pick_algo(d, x, y);
   if (algo == 2) {
     COMA_CHECK(wk_dtype == COMA_BF16, "conv_fwd: MFMA path needs bf16 kernel-layout weights");
     COMA_CHECK(conv_mfma_supported(d, x, y), "conv_fwd: shape not supported by the MFMA path (C=%d N=%d dtype=%d)",
                x->C, y->C, x->dtype);
-    return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes);
+    return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes, wz);
   }
   COMA_CHECK(wk_dtype == COMA_F32, "conv_fwd: fp32 tensors need fp32 kernel-layout weights");
-  if (algo == 3) return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes);
+  if (algo == 3) return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes, wz);
   if (conv_point1_ok(d, x, y)) return conv_point1_fwd(d, x, (const float*)wk, bias, y, s);
   return conv_direct_fwd(d, x, (const float*)wk, bias, y, s);
 }
@@ -92,30 +91,25 @@ extern "C" int coma_conv_wgrad_algo(const coma_conv_desc* d, const coma_tensor* 
   return x->dtype == COMA_BF16 ? 2 : 3;
 }
 
-// conv forward + the statistics of the following BatchNorm(train)/InstanceNorm in one pass where the kernel
-// family supports it (epilogue-fused partial sums), otherwise conv followed by the stand-alone statistics pass.
+// conv forward + the statistics of the following BatchNorm(train)/InstanceNorm in one pass where the kernel family
+// supports it (the epilogue ADDS its {sum, sumsq} to the caller's zeroed fp64 record `sums[G][C][2]`), otherwise conv
+// followed by the stand-alone statistics pass (which adds to the same record).
 extern "C" int coma_conv_fwd_norm_stats(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
-                                        const float* bias, const coma_tensor* y, int32_t mode, float eps, float* mean,
-                                        float* rstd, float* running_mean, float* running_var, float momentum, void* ws,
-                                        size_t ws_bytes, void* stream) {
+                                        const float* bias, const coma_tensor* y, int32_t mode, double* sums, void* ws,
+                                        size_t ws_bytes, int32_t zeroed, void* stream) {
   if (int rc = conv_check(d, x, y)) return rc;
-  COMA_CHECK(wk && mean && rstd && ws && ws_bytes >= coma_norm_ws_bytes(y), "conv_fwd_norm_stats: bad argument");
+  COMA_CHECK(wk && sums, "conv_fwd_norm_stats: bad argument");
   hipStream_t s = (hipStream_t)stream;
   const int algo_ = coma_conv_pick_algo(d, x, y);
   if ((algo_ == 2 && wk_dtype == COMA_BF16) || (algo_ == 3 && wk_dtype == COMA_F32)) {
-    int chunks = 0;
+    int fused = 0;
     const int inst = mode == COMA_NORM_INSTANCE;
-    if (int rc = conv_mfma_fwd(d, x, wk, bias, y, s, (double2*)ws, inst, &chunks, ws, ws_bytes)) return rc;
-    if (chunks > 0) {
-      const int G = inst ? y->B : 1;
-      const int64_t R = inst ? t_vox(y) : t_vox(y) * y->B;
-      return norm_stats_finalize((const double2*)ws, chunks, G, y->C, R, eps, mean, rstd, running_mean, running_var,
-                                 momentum, s);
-    }
+    if (int rc = conv_mfma_fwd(d, x, wk, bias, y, s, (double2*)sums, inst, &fused, ws, ws_bytes, (zeroed & COMA_ZEROED_WS) ? 1 : 0)) return rc;
+    if (fused) return 0;
   } else {
     if (int rc = coma_conv_fwd(d, x, wk, wk_dtype, bias, y, stream)) return rc;
   }
-  return coma_norm_stats(y, mode, eps, mean, rstd, running_mean, running_var, momentum, ws, ws_bytes, stream);
+  return coma_norm_stats(y, mode, sums, stream);
 }
 
 extern "C" size_t coma_conv_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
@@ -125,16 +119,18 @@ extern "C" size_t coma_conv_wgrad_ws_bytes(const coma_conv_desc* d, const coma_t
 }
 
 extern "C" int coma_conv_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk,
-                               float* dbias, void* ws, size_t ws_bytes, void* stream) {
+                               float* dbias, void* ws, size_t ws_bytes, int32_t zeroed, void* stream) {
   if (int rc = conv_check(d, x, dy)) return rc;
   COMA_CHECK(dwk, "conv_wgrad: null dwk");
   hipStream_t s = (hipStream_t)stream;
   if (dbias) {
+    // (the column sums write their partial rows into ws: a pre-zeroed ws is no longer zero afterwards)
     COMA_CHECK(ws && ws_bytes >= coma_norm_ws_bytes(dy), "conv_wgrad: workspace too small for the bias gradient");
     if (int rc = colsum(dy, d->per_sample_w, dbias, ws, ws_bytes, s)) return rc;
+    zeroed &= ~COMA_ZEROED_WS;
   }
-  if (conv_point1_ok(d, x, dy)) return conv_point1_wgrad(d, x, dy, dwk, s);
+  if (conv_point1_ok(d, x, dy)) return conv_point1_wgrad(d, x, dy, dwk, s, zeroed);
   const int algo = coma_conv_wgrad_algo(d, x, dy);
-  if (algo >= 2) return conv_mfma_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
-  return conv_direct_wgrad(d, x, dy, dwk, s);
+  if (algo >= 2) return conv_mfma_wgrad(d, x, dy, dwk, ws, ws_bytes, s, zeroed);
+  return conv_direct_wgrad(d, x, dy, dwk, s, zeroed);
 }

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_k(WgradP p) {
 }
 
 int conv_direct_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk,
-                      hipStream_t s) {
+                      hipStream_t s, int zeroed) {
   WgradP p;
   p.x = x->data; p.ldx = x->ld; p.sbx = x->sb; p.Di = x->D; p.Hi = x->H; p.Wi = x->W; p.C = x->C;
   p.dy = dy->data; p.ldy = dy->ld; p.sby = dy->sb; p.Do = dy->D; p.Ho = dy->H; p.Wo = dy->W; p.N = dy->C;
@@ -227,7 +227,7 @@ int conv_direct_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_
   p.dwk = dwk; p.wsb = d->per_sample_w ? wsz : 0;
   p.k = d->ksize; p.stride = d->stride; p.pad = d->pad; p.form = d->form;
   const int Bw = d->per_sample_w ? x->B : 1;
-  if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz * Bw, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  if (!(zeroed & COMA_ZEROED_OUT) && hipMemsetAsync(dwk, 0, sizeof(float) * wsz * Bw, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
   const int64_t M = (int64_t)dy->D * dy->H * dy->W;
   const int big = dy->C > x->C ? dy->C : x->C;
   const int TS = big > 32 ? 4 : (big > 16 ? 2 : 1);

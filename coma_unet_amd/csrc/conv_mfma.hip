@@ -47,6 +47,13 @@ struct GatherP {
   float* part; long part_sb;           //      whose fp32 partial tiles are merged atomically into part[b][voxel][N]
 };
 
+// fused norm statistics: a block ADDS its {sum, sumsq} of one (group, channel) to the caller's zeroed fp64 record
+// (global_atomic_add_f64; every consumer derives mean / rstd from the record: norm.hip, NormStat)
+__device__ __forceinline__ void stat_add(double2* rec, double a, double c) {
+  unsafeAtomicAdd(&rec->x, a);
+  unsafeAtomicAdd(&rec->y, c);
+}
+
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 2) | (chunk ^ ((row >> 2) & 3)); }  // 16-B slot index
 
 // blockIdx -> work-item remap: the dispatcher deals consecutive blocks round-robin over the 8 XCDs
@@ -643,12 +650,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   int id = id_begin, tix = 0, tiy = 0, tiz = 0;
   while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
   if (id >= id_end) {        // nothing to do for this block (padding ids): still publish a zero partial
-    if (p.stats && tid < 32 && n0 + tid < p.N) {
-      const int G = p.stats_inst ? gridDim.z : 1;
-      const int chunk = p.stats_inst ? blockIdx.x : blockIdx.x + gridDim.x * b;
-      p.stats[((long)chunk * G + (p.stats_inst ? b : 0)) * p.N + n0 + tid] = make_double2(0.0, 0.0);
-    }
-    return;
+    return;      // (nothing to add to the statistics record)
   }
   if (RESIDENT == 1) { load_w(0, 0); store_w(); }
   load_halo(tiz * TZ, tiy * TY, tix * TX, 0);
@@ -960,10 +962,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
     if (tid < 32 && n0 + tid < p.N) {
       double a = 0.0, c = 0.0;
       for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
-      const int G = p.stats_inst ? gridDim.z : 1;
       const int g = p.stats_inst ? b : 0;
-      const int chunk = p.stats_inst ? blockIdx.x : blockIdx.x + gridDim.x * b;
-      p.stats[((long)chunk * G + g) * p.N + n0 + tid] = make_double2(a, c);
+      stat_add(p.stats + ((long)g * p.N + n0 + tid), a, c);
     }
   }
 }
@@ -1245,10 +1245,8 @@ __global__ __launch_bounds__(256, 2) void conv_thin16_k(Thin16P p) {
     if (tid < NB * 16 && tid < p.N) {
       double a = 0.0, c = 0.0;
       for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
-      const int G = p.stats_inst ? gridDim.z : 1;
       const int g = p.stats_inst ? b : 0;
-      const int chunk = p.stats_inst ? blockIdx.x : blockIdx.x + gridDim.x * b;
-      p.stats[((long)chunk * G + g) * p.N + tid] = make_double2(a, c);
+      stat_add(p.stats + ((long)g * p.N + tid), a, c);
     }
   }
 }
@@ -1458,10 +1456,8 @@ __global__ __launch_bounds__(256, 2) void conv_thin16f_k(Thin16FP p) {
     if (tid < NB * 16 && tid < p.N) {
       double a = 0.0, c = 0.0;
       for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
-      const int G = p.stats_inst ? gridDim.z : 1;
       const int g = p.stats_inst ? b : 0;
-      const int chunk = p.stats_inst ? blockIdx.x : blockIdx.x + gridDim.x * b;
-      p.stats[((long)chunk * G + g) * p.N + tid] = make_double2(a, c);
+      stat_add(p.stats + ((long)g * p.N + tid), a, c);
     }
   }
 }
@@ -1492,10 +1488,7 @@ static int conv_thin16f(const coma_conv_desc* d, const coma_tensor* x, const voi
   q.ids_per_block = (q.ids_total + gx - 1) / gx;
   gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
   q.stats = nullptr; q.stats_inst = stats_inst;
-  if (stats && gx * (stats_inst ? 1 : x->B) <= 1024 / (stats_inst ? x->B : 1)) {
-    q.stats = stats;
-    *stats_chunks = stats_inst ? gx : gx * x->B;
-  }
+  if (stats) { q.stats = stats; *stats_chunks = 1; }
   const dim3 grid((unsigned)gx, 1, (unsigned)x->B);
   const bool c16 = q.C > 8, n32 = q.N > 16;
   const int cp = c16 ? 16 : q.C > 4 ? 8 : 4, wrow = n32 ? 32 : 16;      // (C <= 4: one MFMA per tap)
@@ -1632,10 +1625,8 @@ __global__ __launch_bounds__(256) void conv_mfma_pw_k(PwP p) {
     if (tid < NT * 32 && tid < p.N) {
       double a = 0.0, c = 0.0;
       for (int w = 0; w < 4; ++w) { a += (double)red[(w * 64 + tid) * 2]; c += (double)red[(w * 64 + tid) * 2 + 1]; }
-      const int G = p.stats_inst ? gridDim.y : 1;
       const int g = p.stats_inst ? b : 0;
-      const int chunk = p.stats_inst ? blockIdx.x : blockIdx.x + gridDim.x * b;
-      p.stats[((long)chunk * G + g) * p.N + tid] = make_double2(a, c);
+      stat_add(p.stats + ((long)g * p.N + tid), a, c);
     }
   }
 }
@@ -1708,7 +1699,7 @@ static int gather_ksplit(long blocks, int nsteps, bool f32 = false) {
 }
 
 template <int BN, typename T>
-static int launch_gather(const GatherP& p0, int mode, int B, hipStream_t s, void* ws, size_t ws_bytes) {
+static int launch_gather(const GatherP& p0, int mode, int B, hipStream_t s, void* ws, size_t ws_bytes, int ws_zeroed) {
   GatherP p = p0;
   constexpr int BM = (BN == 128) ? 128 : 256;
   constexpr int LCK = elem<T>::EPB == 8 ? 5 : 4;
@@ -1721,7 +1712,7 @@ static int launch_gather(const GatherP& p0, int mode, int B, hipStream_t s, void
   p.part = nullptr; p.part_sb = 0;
   if (p.ksplit > 1 && ws && ws_bytes >= sizeof(float) * (size_t)B * Vout * p.N) {
     p.part = (float*)ws; p.part_sb = Vout * p.N;
-    if (hipMemsetAsync(ws, 0, sizeof(float) * (size_t)B * Vout * p.N, s) != hipSuccess) { coma_set_error("conv split-K memset failed"); return 2; }
+    if (!ws_zeroed && hipMemsetAsync(ws, 0, sizeof(float) * (size_t)B * Vout * p.N, s) != hipSuccess) { coma_set_error("conv split-K memset failed"); return 2; }
   } else p.ksplit = 1;
   dim3 grid(gx, gy * p.ksplit, (unsigned)B);
   coma_set_kernel_tag("conv_mfma_gather_k<%d, %d, %s>", BN, mode, LCK == 4 ? "float" : "__bf16");
@@ -1792,10 +1783,7 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
       q.ids_per_block = (q.ids_total + gx - 1) / gx;
       gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
       q.stats = nullptr; q.stats_inst = stats_inst;
-      if (stats && gx * (stats_inst ? 1 : x->B) <= 1024 / (stats_inst ? x->B : 1)) {
-        q.stats = stats;
-        *stats_chunks = stats_inst ? gx : gx * x->B;
-      }
+      if (stats) { q.stats = stats; *stats_chunks = 1; }
       dim3 grid((unsigned)gx, 1, (unsigned)x->B);
       const bool c16 = q.C > 8, n32 = q.N > 16;
       size_t lds = (size_t)34 * 6 * 4 * (c16 ? 32 : 16);
@@ -1830,10 +1818,7 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     q.ids_per_block = (q.ids_total + gx - 1) / gx;
     gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
     dim3 grid((unsigned)gx, (unsigned)nblk_n, (unsigned)x->B);
-    if (stats && gx * (stats_inst ? 1 : x->B) <= 1024 / (stats_inst ? x->B : 1)) {
-      q.stats = stats;
-      *stats_chunks = stats_inst ? gx : gx * x->B;
-    }
+    if (stats) { q.stats = stats; *stats_chunks = 1; }
     constexpr int HV2 = 34 * 6 * 4;
     const bool resident = thin || (!F32 && q.C == 32);
     // C >= 64: all 27 taps of the current 32-channel chunk in LDS, refetched per chunk (RESIDENT = 2).  The 9-taps-per-
@@ -1893,7 +1878,7 @@ size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, con
 
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                   const coma_tensor* y, hipStream_t s, double2* stats, int stats_inst, int* stats_chunks, void* ws,
-                  size_t ws_bytes) {
+                  size_t ws_bytes, int ws_zeroed) {
   const bool f32 = x->dtype == COMA_F32;
   if (f32 && thin16f_ok(d, x, y)) return conv_thin16f(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
   if (f32) { if (f32_halo_ok(d, x, y)) return conv_mfma_halo<float>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks); }
@@ -1910,12 +1895,7 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
     long nb = ((q.V + 31) / 32 + 3) / 4;
     if (nb > 2048) nb = 2048;
     q.stats = nullptr; q.stats_inst = stats_inst;
-    if (stats) {                                   // the statistics workspace holds 1024 (chunk, group) partial rows
-      const long cap = 1024 / x->B;
-      if (nb > cap) nb = cap;
-      q.stats = stats;
-      *stats_chunks = stats_inst ? (int)nb : (int)nb * x->B;
-    }
+    if (stats) { q.stats = stats; *stats_chunks = 1; }
     dim3 grid((unsigned)nb, (unsigned)x->B);
     coma_set_kernel_tag("conv_mfma_pw_k<%d, %d>", ks > 4 ? 4 : ks, nt);
 #define PWL(K_, N_) hipLaunchKernelGGL((conv_mfma_pw_k<K_, N_>), grid, dim3(256), 0, s, q)
@@ -1942,13 +1922,13 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
     p.Mz = y->D; p.My = y->H; p.Mx = y->W;
   }
   if (f32) {
-    if (y->C % 128 == 0) return launch_gather<128, float>(p, mode, x->B, s, ws, ws_bytes);
-    if (y->C % 64 == 0) return launch_gather<64, float>(p, mode, x->B, s, ws, ws_bytes);
-    return launch_gather<32, float>(p, mode, x->B, s, ws, ws_bytes);
+    if (y->C % 128 == 0) return launch_gather<128, float>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
+    if (y->C % 64 == 0) return launch_gather<64, float>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
+    return launch_gather<32, float>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
   }
-  if (y->C % 128 == 0) return launch_gather<128, bf16_t>(p, mode, x->B, s, ws, ws_bytes);
-  if (y->C % 64 == 0) return launch_gather<64, bf16_t>(p, mode, x->B, s, ws, ws_bytes);
-  return launch_gather<32, bf16_t>(p, mode, x->B, s, ws, ws_bytes);
+  if (y->C % 128 == 0) return launch_gather<128, bf16_t>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
+  if (y->C % 64 == 0) return launch_gather<64, bf16_t>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
+  return launch_gather<32, bf16_t>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
 }
 
 // =====================================================================================
@@ -2974,7 +2954,7 @@ static bool thin16_wgrad_ok(const coma_conv_desc* d, const coma_tensor* x, const
 }
 
 static int conv_thin16_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws,
-                             size_t ws_bytes, hipStream_t s) {
+                             size_t ws_bytes, hipStream_t s, int zeroed) {
   Thin16WP q;
   q.x = (const bf16_t*)x->data; q.ldx = (int)x->ld; q.sbx = x->sb; q.D = x->D; q.H = x->H; q.W = x->W; q.C = x->C;
   q.dy = (const bf16_t*)dy->data; q.ldn = (int)dy->ld; q.sbn = dy->sb; q.N = dy->C;
@@ -2993,7 +2973,7 @@ static int conv_thin16_wgrad(const coma_conv_desc* d, const coma_tensor* x, cons
   q.nrep = replicas ? WGRAD_NREP : 1;
   q.rep_stride = replicas ? wsz : 0;
   q.dwk = replicas ? (float*)ws : dwk;
-  if (hipMemsetAsync(q.dwk, 0, sizeof(float) * wsz * q.nrep, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  if (!(zeroed & (replicas ? COMA_ZEROED_WS : COMA_ZEROED_OUT)) && hipMemsetAsync(q.dwk, 0, sizeof(float) * wsz * q.nrep, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
   const int cp = q.C > 8 ? 16 : 8, nb = q.N > 16 ? 2 : 1;
   const int nm = cp == 16 ? 27 : 14;
   size_t lds = (size_t)(34 * 6 * 4 + 2) * cp * 2 + (size_t)256 * nb * 16 * 2;
@@ -3155,7 +3135,7 @@ static bool f32_wgrad16_ok(const coma_conv_desc* d, const coma_tensor* x, const 
          (unsigned long long)t_vox(x) * x->ld * 4 < 0x7fff0000ull && (unsigned long long)t_vox(dy) * dy->ld * 4 < 0x7fff0000ull;
 }
 
-static int conv_f32_wgrad16(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s) {
+static int conv_f32_wgrad16(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s, int zeroed) {
   const coma_tensor* dn = d->form == 0 ? dy : x;
   const coma_tensor* ga = d->form == 0 ? x : dy;
   F32W16P q;
@@ -3178,7 +3158,7 @@ static int conv_f32_wgrad16(const coma_conv_desc* d, const coma_tensor* x, const
   const long wsz1 = 27L * q.N * q.C, wsz = wsz1 * (d->per_sample_w ? x->B : 1);
   q.wsb = d->per_sample_w ? wsz1 : 0;
   q.dwk = dwk;
-  if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  if (!(zeroed & COMA_ZEROED_OUT) && hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
   const size_t lds = S == 1 ? (size_t)(34 * 6 * 4 + 256) * 32 * 4 : (size_t)(65 * 5 * 3 + 64) * 32 * 4;
   static bool attr = false;
   if (!attr) {
@@ -3365,7 +3345,7 @@ static bool bf16_wgrad16_ok(const coma_conv_desc* d, const coma_tensor* x, const
          (unsigned long long)t_vox(x) * x->ld * 2 < 0x7fff0000ull && (unsigned long long)t_vox(dy) * dy->ld * 2 < 0x7fff0000ull;
 }
 
-static int conv_bf16_wgrad16(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s) {
+static int conv_bf16_wgrad16(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s, int zeroed) {
   const coma_tensor* dn = d->form == 0 ? dy : x;
   const coma_tensor* ga = d->form == 0 ? x : dy;
   B16W16P q;
@@ -3387,7 +3367,7 @@ static int conv_bf16_wgrad16(const coma_conv_desc* d, const coma_tensor* x, cons
   const long wsz1 = 27L * q.N * q.C, wsz = wsz1 * (d->per_sample_w ? x->B : 1);
   q.wsb = d->per_sample_w ? wsz1 : 0;
   q.dwk = dwk;
-  if (hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  if (!(zeroed & COMA_ZEROED_OUT) && hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
   const size_t lds = S == 1 ? (size_t)(34 * 6 * 4 + 256) * 64 : (size_t)(65 * 5 * 3 + 64) * 64;
   static bool attr = false;
   if (!attr) {
@@ -3415,7 +3395,7 @@ static bool thin16f_wgrad_ok(const coma_conv_desc* d, const coma_tensor* x, cons
 }
 
 static int conv_thin16f_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws,
-                              size_t ws_bytes, hipStream_t s) {
+                              size_t ws_bytes, hipStream_t s, int zeroed) {
   Thin16FWP q;
   q.x = (const float*)x->data; q.ldx = (int)x->ld; q.sbx = x->sb; q.D = x->D; q.H = x->H; q.W = x->W; q.C = x->C;
   q.dy = (const float*)dy->data; q.ldn = (int)dy->ld; q.sbn = dy->sb; q.N = dy->C;
@@ -3434,7 +3414,7 @@ static int conv_thin16f_wgrad(const coma_conv_desc* d, const coma_tensor* x, con
   q.nrep = replicas ? WGRAD_NREP : 1;
   q.rep_stride = replicas ? wsz : 0;
   q.dwk = replicas ? (float*)ws : dwk;
-  if (hipMemsetAsync(q.dwk, 0, sizeof(float) * wsz * q.nrep, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  if (!(zeroed & (replicas ? COMA_ZEROED_WS : COMA_ZEROED_OUT)) && hipMemsetAsync(q.dwk, 0, sizeof(float) * wsz * q.nrep, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
   const int cp = q.C > 8 ? 16 : q.C > 4 ? 8 : 4, nb = q.N > 16 ? 2 : 1;
   const int nm = (27 + 16 / cp - 1) / (16 / cp);
   size_t lds = (size_t)34 * 6 * 4 * cp * 4 + (size_t)256 * nb * 16 * 4;
@@ -3462,7 +3442,7 @@ static int conv_thin16f_wgrad(const coma_conv_desc* d, const coma_tensor* x, con
 }
 
 static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws,
-                            size_t ws_bytes, hipStream_t s) {
+                            size_t ws_bytes, hipStream_t s, int zeroed) {
   Wgrad2P p;
   p.dyp = (const bf16_t*)dy->data; p.ldn = (int)dy->ld; p.sbn = dy->sb;
   p.xp = (const bf16_t*)x->data; p.ldc = (int)x->ld; p.sbc = x->sb;
@@ -3491,7 +3471,7 @@ static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const
   p.nrep = replicas ? WGRAD_NREP : 1;
   p.rep_stride = replicas ? wsz : 0;
   if (replicas) p.dwk = (float*)ws;
-  if (hipMemsetAsync(p.dwk, 0, sizeof(float) * wsz * p.nrep, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  if (!(zeroed & (replicas ? COMA_ZEROED_WS : COMA_ZEROED_OUT)) && hipMemsetAsync(p.dwk, 0, sizeof(float) * wsz * p.nrep, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
   const size_t lds = (size_t)(256 + (d->ksize == 3 ? 816 + 1 : 256)) * 64;   // +1 row: the unused packed column reads one voxel past the halo
   static bool attr = false;
   if (!attr) {
@@ -3611,18 +3591,20 @@ size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, c
   return (wgrad2_ok(d, x, dy) || x->dtype == COMA_F32) && wsz <= WGRAD_REP_MAX_ELEMS ? sizeof(float) * wsz * WGRAD_NREP : 0;
 }
 
+// zeroed: COMA_ZEROED_OUT -- dwk is all zeros on entry; COMA_ZEROED_WS -- the first conv_mfma_wgrad_ws_bytes() bytes of ws are
+// (the caller's pre-zeroed arena: one memset per training step instead of one per layer)
 int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, void* ws, size_t ws_bytes,
-                    hipStream_t s) {
-  if (thin16_wgrad_ok(d, x, dy)) return conv_thin16_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
-  if (bf16_wgrad16_ok(d, x, dy)) return conv_bf16_wgrad16(d, x, dy, dwk, s);
-  if (wgrad2_ok(d, x, dy)) return conv_mfma_wgrad2(d, x, dy, dwk, ws, ws_bytes, s);
-  if (thin16f_wgrad_ok(d, x, dy)) return conv_thin16f_wgrad(d, x, dy, dwk, ws, ws_bytes, s);
-  if (f32_wgrad16_ok(d, x, dy)) return conv_f32_wgrad16(d, x, dy, dwk, s);
+                    hipStream_t s, int zeroed) {
+  if (thin16_wgrad_ok(d, x, dy)) return conv_thin16_wgrad(d, x, dy, dwk, ws, ws_bytes, s, zeroed);
+  if (bf16_wgrad16_ok(d, x, dy)) return conv_bf16_wgrad16(d, x, dy, dwk, s, zeroed);
+  if (wgrad2_ok(d, x, dy)) return conv_mfma_wgrad2(d, x, dy, dwk, ws, ws_bytes, s, zeroed);
+  if (thin16f_wgrad_ok(d, x, dy)) return conv_thin16f_wgrad(d, x, dy, dwk, ws, ws_bytes, s, zeroed);
+  if (f32_wgrad16_ok(d, x, dy)) return conv_f32_wgrad16(d, x, dy, dwk, s, zeroed);
   WgradPlan pl = wgrad_plan(d, x, dy);
   COMA_CHECK(pl.ok, "conv_mfma_wgrad: unsupported problem");
   pl.p.dwk = dwk;
   const long wsz = (long)d->ksize * d->ksize * d->ksize * dy->C * x->C * (d->per_sample_w ? x->B : 1);
-  if (!pl.p.plain && hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  if (!pl.p.plain && !(zeroed & COMA_ZEROED_OUT) && hipMemsetAsync(dwk, 0, sizeof(float) * wsz, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
   if (x->dtype == COMA_F32) {
     // small outputs (the 1..16-channel layers): hundreds of blocks merging into a few cache lines serialise in the
     // atomic unit -- they merge into WGRAD_NREP replicas in the workspace, summed by one small kernel (as wgrad2 does)
@@ -3631,7 +3613,7 @@ int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_te
     pl.p.rep_stride = replicas ? wsz : 0;
     if (replicas) {
       pl.p.dwk = (float*)ws;
-      if (hipMemsetAsync(ws, 0, sizeof(float) * wsz * WGRAD_NREP, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+      if (!(zeroed & COMA_ZEROED_WS) && hipMemsetAsync(ws, 0, sizeof(float) * wsz * WGRAD_NREP, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
     }
     const int taps = d->ksize * d->ksize * d->ksize, tpt = 32 / pl.p.cp, ntiles = (taps + tpt - 1) / tpt;
     const int nt = (ntiles + 3) / 4;                  // tiles per wave: 27 -> 7, 14 -> 4, 7 -> 2, <= 4 -> 1

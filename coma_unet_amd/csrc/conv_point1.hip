@@ -202,7 +202,7 @@ int conv_point1_fwd(const coma_conv_desc* d, const coma_tensor* x, const float* 
 }
 
 // dwk [Bw][1][N][C] with N == 1 or C == 1: a K-vector per sample group
-int conv_point1_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s) {
+int conv_point1_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk, hipStream_t s, int zeroed) {
   P1 p{};
   p.V = t_vox(x);
   const coma_tensor* a = dy->C == 1 ? x : dy;      // the K-channel side
@@ -212,7 +212,7 @@ int conv_point1_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_
   p.dw = dwk; p.dwsb = d->per_sample_w ? a->C : 0;
   p.cp = pieces(a);
   const int Bw = d->per_sample_w ? x->B : 1;
-  if (hipMemsetAsync(dwk, 0, sizeof(float) * a->C * Bw, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
+  if (!(zeroed & COMA_ZEROED_OUT) && hipMemsetAsync(dwk, 0, sizeof(float) * a->C * Bw, s) != hipSuccess) { coma_set_error("wgrad memset failed"); return 2; }
   unsigned nb = p1_grid(p.V, p.cp);
   if (nb > 512) nb = 512;
   dim3 grid(nb, (unsigned)x->B);

@@ -90,6 +90,54 @@ extern "C" int coma_add_relu_bwd(const coma_tensor* out, const coma_tensor* dout
   return run_ew3<OP_RELU_BWD>(out, dout, da, (hipStream_t)stream);
 }
 
+// dst = T_dst(src): the model's input staging -- the external fp32 volume (B, C, D, H, W) with C == 1 IS a channels-last
+// (B, D, H, W, 1) tensor; this writes it into the (pitch-8 padded) bf16 / fp32 internal buffer in one pass instead of an
+// ATen strided-copy kernel (35 us at 2 x 128^3: attn_unet_data_parallel.py:661, the model's first touch of x)
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_copy_k(const TS* src, int64_t lds_, int64_t sbs, TD* dst, int64_t ldd, int64_t sbd,
+                                                   int64_t V, int C) {
+  const int b = blockIdx.y;
+  const int64_t total = V * C;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t v = C == 1 ? e : e / C; const int c = C == 1 ? 0 : (int)(e - v * C);
+    st_f(dst + b * sbd + v * ldd + c, ld_f(src + b * sbs + v * lds_ + c));
+  }
+}
+extern "C" int coma_cast_copy(const coma_tensor* src, const coma_tensor* dst, void* stream) {
+  COMA_CHECK(src && dst && src->data && dst->data, "cast_copy: null argument");
+  COMA_CHECK(t_same_grid(src, dst) && src->C == dst->C, "cast_copy: shape mismatch");
+  const int64_t V = t_vox(src);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(ew_grid(V * src->C), src->B);
+#define L(TS, TD) hipLaunchKernelGGL((cast_copy_k<TS, TD>), grid, dim3(256), 0, s, (const TS*)src->data, src->ld, src->sb, \
+                                     (TD*)dst->data, dst->ld, dst->sb, V, src->C)
+  if (src->dtype == COMA_F32) { if (dst->dtype == COMA_F32) L(float, float); else L(float, bf16_t); }
+  else { if (dst->dtype == COMA_F32) L(bf16_t, float); else L(bf16_t, bf16_t); }
+#undef L
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// base[off .. off + len) = 0 for every (off, len) row of a device table: ONE launch clears the slots of the flat gradient
+// buffer that no backward kernel overwrites (the optimizer's zero_grad; the rest of the buffer is written with "=")
+__global__ __launch_bounds__(256) void zero_ranges_k(float* __restrict__ base, const int64_t* __restrict__ ranges, int n) {
+  for (int r = blockIdx.y; r < n; r += gridDim.y) {
+    float* p = base + ranges[2 * r];
+    const int64_t len = ranges[2 * r + 1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+  }
+}
+extern "C" int coma_zero_ranges(float* base, const int64_t* ranges, int32_t n, int64_t max_len, void* stream) {
+  COMA_CHECK(base && ranges && n >= 0, "zero_ranges: bad argument");
+  if (n == 0) return 0;
+  int64_t gx = (max_len + 255) / 256;
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(zero_ranges_k, dim3((unsigned)gx, (unsigned)(n > 1024 ? 1024 : n)), dim3(256), 0, (hipStream_t)stream, base, ranges, n);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
 // dst[0] = sum_b src[b]
 template <typename T>
 __global__ __launch_bounds__(256) void batch_sum_k(const T* src, int64_t lds_, int64_t sbs, int B, T* dst, int64_t ldd,

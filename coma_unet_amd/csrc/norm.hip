@@ -55,9 +55,31 @@ struct RowWalk {
   }
 };
 
-// partial[(chunk*G + g)*C + c] = {sum, sumsq} over the chunk's rows
+// ---- how a kernel obtains (mean, rstd) of (group g, channel c) -------------------------------------------------------
+// Training statistics travel as fp64 {sum, sumsq} records `sums[G][C][2]` that the producers (the convolution epilogues,
+// stats_partial_k) ADD to with global_atomic_add_f64 -- the caller hands over a zeroed record -- and every consumer derives
+// mean / rstd from on the fly: no finalise launch between the statistics pass and the apply pass, no partial buffers.
+// (fp64 sums of per-block fp64 partials: the order of the atomic adds moves the result by ~1e-16 relative, far below the
+// fp32 mean / rstd every consumer rounds to.)  Eval-mode BatchNorm passes fp32 mean / rstd arrays instead.
+struct NormStat {
+  const double* sums; double R; float eps;
+  const float* mean; const float* rstd;
+};
+__device__ __forceinline__ void norm_mr(const NormStat& q, int i, float& mu, float& rs) {
+  if (q.sums) {
+    const double m = q.sums[2 * i] / q.R;
+    double var = q.sums[2 * i + 1] / q.R - m * m;
+    if (var < 0.0) var = 0.0;
+    mu = (float)m;
+    rs = (float)(1.0 / sqrt(var + (double)q.eps));
+  } else { mu = q.mean[i]; rs = q.rstd[i]; }
+}
+
+__device__ __forceinline__ void add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }      // global_atomic_add_f64
+
+// sums[(g*C + c)*2 .. +2] += {sum, sumsq} over the block's chunk of rows
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double2* partial) {
+__global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double* sums, double2* partial) {
   __shared__ double sh[256][2 * VEC];
   const int tid = threadIdx.x, tx = tid % p.cvp, ty = tid / p.cvp;
   const int g = blockIdx.y;
@@ -70,25 +92,37 @@ __global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double2* partial
     const T* base = reinterpret_cast<const T*>(p.x);
     // bf16 volumes: fp32 sums over bursts of 8 rows, folded into the fp64 accumulators (an 8-term fp32 sum of
     // bf16-sized data loses nothing that matters; the long reduction stays fp64).  fp32 volumes: every term goes
-    // straight to fp64 (burst of 1), as the exact-fp32 mode's gradient parity needs.
-    constexpr int BURST = sizeof(T) == 2 ? 8 : 1;
+    // straight to fp64, as the exact-fp32 mode's gradient parity needs.  Either way the burst's loads are issued
+    // together (rows past the chunk re-read its last row and are masked): 4-8 requests of 16 bytes in flight per lane.
+    constexpr int BURST = sizeof(T) == 2 ? 8 : 4;
     RowWalk w(p, r0 + ty);
     while (w.r < r1) {
-      float fs[VEC], fq[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) { fs[j] = 0.f; fq[j] = 0.f; }
+      float v[BURST][VEC];
+      bool ok[BURST];
+      int64_t off = w.off(p, g, p.ld, p.sb);
 #pragma unroll
       for (int u = 0; u < BURST; ++u) {
-        if (w.r < r1) {
-          float v[VEC];
-          vec_io<T, VEC>::load(base + w.off(p, g, p.ld, p.sb) + tx * VEC, v);
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) { fs[j] += v[j]; fq[j] = fmaf(v[j], v[j], fq[j]); }
-          w.step(p);
-        }
+        ok[u] = w.r < r1;
+        if (ok[u]) off = w.off(p, g, p.ld, p.sb);
+        vec_io<T, VEC>::load(base + off + tx * VEC, v[u]);
+        w.step(p);
       }
+      if (sizeof(T) == 2) {
+        float fs[VEC], fq[VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { s[j] += (double)fs[j]; q[j] += (double)fq[j]; }
+        for (int j = 0; j < VEC; ++j) { fs[j] = 0.f; fq[j] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < BURST; ++u)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { const float t = ok[u] ? v[u][j] : 0.f; fs[j] += t; fq[j] = fmaf(t, t, fq[j]); }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { s[j] += (double)fs[j]; q[j] += (double)fq[j]; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < BURST; ++u)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { const float t = ok[u] ? v[u][j] : 0.f; s[j] += (double)t; q[j] += (double)(t * t); }
+      }
     }
   }
 #pragma unroll
@@ -105,8 +139,11 @@ __global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double2* partial
   }
   if (ty == 0 && tx < p.cv) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j)
-      partial[((int64_t)blockIdx.x * p.G + g) * p.C + tx * VEC + j] = make_double2(sh[tid][2 * j], sh[tid][2 * j + 1]);
+    for (int j = 0; j < VEC; ++j) {
+      const int64_t i = (int64_t)g * p.C + tx * VEC + j;
+      if (sums) { add_f64(sums + 2 * i, sh[tid][2 * j]); add_f64(sums + 2 * i + 1, sh[tid][2 * j + 1]); }
+      else partial[((int64_t)blockIdx.x * p.G + g) * p.C + tx * VEC + j] = make_double2(sh[tid][2 * j], sh[tid][2 * j + 1]);   // (colsum / spatial mean)
+    }
   }
 }
 
@@ -115,36 +152,20 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// one wave per (group, channel): lanes stride over the chunk partials, fixed-order butterfly
-__global__ __launch_bounds__(256) void stats_finalize_k(const double2* partial, int nchunks, int G, int C, int64_t R, float eps,
-                                 float* mean, float* rstd, float* rmean, float* rvar, float momentum) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (i >= G * C) return;
-  double s = 0.0, q = 0.0;
-  for (int k = lane; k < nchunks; k += 64) { const double2 v = partial[(int64_t)k * G * C + i]; s += v.x; q += v.y; }
-  s = wave_sum(s); q = wave_sum(q);
-  if (lane != 0) return;
-  const double m = s / (double)R;
-  double var = q / (double)R - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[i] = (float)m;
-  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-  if (rmean && G == 1) {
-    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
-    rmean[i] = (1.f - momentum) * rmean[i] + momentum * (float)m;
-    rvar[i] = (1.f - momentum) * rvar[i] + momentum * (float)unb;
-  }
-}
-
 struct ApplyP {
   const void* x; int64_t ldx, sbx;
   void* y; int64_t ldy, sby;
   const void* dy; int64_t lddy, sbdy;
   int64_t V; int B, C, cv; int inst;
-  const float *mean, *rstd, *gamma, *beta, *slope;
+  NormStat st;
+  const float *gamma, *beta, *slope;
   int act;
+  float *rmean, *rvar; float momentum;      // forward, BatchNorm(train): running statistics updated by block (0, 0)
+  const double* bsums;                      // backward: [G][C][3] {sum dz, sum dz*xhat, sum dy*dact/dslope}
+  float *dgamma, *dbeta, *dslope;           // backward: written by block (0, 0)
 };
+
+constexpr int NORM_UNR = 4;      // voxels per lane and loop trip of the apply kernels: their loads are issued together
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void norm_act_fwd_k(ApplyP p) {
@@ -154,6 +175,17 @@ __global__ __launch_bounds__(256) void norm_act_fwd_k(ApplyP p) {
   const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.sbx;
   T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * p.sby;
   const int g = p.inst ? b : 0;
+  if (p.rmean && blockIdx.x == 0 && b == 0) {
+    // BatchNorm3d(train): running_mean / running_var <- (1 - m) * old + m * {batch mean, unbiased batch variance}
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+      const double m = p.st.sums[2 * c] / p.st.R;
+      double var = p.st.sums[2 * c + 1] / p.st.R - m * m;
+      if (var < 0.0) var = 0.0;
+      const double unb = p.st.R > 1.0 ? var * p.st.R / (p.st.R - 1.0) : var;
+      p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * (float)m;
+      p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)unb;
+    }
+  }
   const int64_t stride = (int64_t)gridDim.x * 256, e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (stride % p.cv == 0) {
     // the thread keeps its channel group for the whole sweep: scale / shift live in registers, no division in the loop
@@ -161,12 +193,26 @@ __global__ __launch_bounds__(256) void norm_act_fwd_k(ApplyP p) {
     float sc[VEC], sh[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const float rs = p.rstd[g * p.C + c0 + j], ga = p.gamma ? p.gamma[c0 + j] : 1.f;
+      float mu, rs; norm_mr(p.st, g * p.C + c0 + j, mu, rs);
+      const float ga = p.gamma ? p.gamma[c0 + j] : 1.f;
       sc[j] = rs * ga;
-      sh[j] = (p.gamma ? p.beta[c0 + j] : 0.f) - p.mean[g * p.C + c0 + j] * rs * ga;
+      sh[j] = (p.gamma ? p.beta[c0 + j] : 0.f) - mu * rs * ga;
     }
     const int64_t dv = stride / p.cv;
-    for (int64_t v = e0 / p.cv; v < p.V; v += dv) {
+    int64_t v = e0 / p.cv;
+    for (; v + (NORM_UNR - 1) * dv < p.V; v += NORM_UNR * dv) {
+      float xv[NORM_UNR][VEC];
+#pragma unroll
+      for (int u = 0; u < NORM_UNR; ++u) vec_io<T, VEC>::load(xb + (v + u * dv) * p.ldx + c0, xv[u]);
+#pragma unroll
+      for (int u = 0; u < NORM_UNR; ++u) {
+        float yv[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) yv[j] = act_fwd(p.act, fmaf(xv[u][j], sc[j], sh[j]), a);
+        vec_io<T, VEC>::store(yb + (v + u * dv) * p.ldy + c0, yv);
+      }
+    }
+    for (; v < p.V; v += dv) {
       float xv[VEC], yv[VEC];
       vec_io<T, VEC>::load(xb + v * p.ldx + c0, xv);
 #pragma unroll
@@ -182,20 +228,20 @@ __global__ __launch_bounds__(256) void norm_act_fwd_k(ApplyP p) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int c = c0 + j;
-      float z = (xv[j] - p.mean[g * p.C + c]) * p.rstd[g * p.C + c];
-      if (p.gamma) z = z * p.gamma[c] + p.beta[c];
-      yv[j] = act_fwd(p.act, z, a);
+      float mu, rs; norm_mr(p.st, g * p.C + c, mu, rs);
+      const float ga = p.gamma ? p.gamma[c] : 1.f;
+      const float sc = rs * ga, sh = (p.gamma ? p.beta[c] : 0.f) - mu * rs * ga;     // (the same arithmetic as the fast path)
+      yv[j] = act_fwd(p.act, fmaf(xv[j], sc, sh), a);
     }
     vec_io<T, VEC>::store(yb + v * p.ldy + c0, yv);
   }
 }
 
-// backward pass 1: per (g,c) partial {sum dz, sum dz*xhat, sum dy*dact/dslope}
+// backward pass 1: bsums[(g*C + c)*3 .. +3] += {sum dz, sum dz*xhat, sum dy*dact/dslope} over the block's rows
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* dyp, int64_t lddy, int64_t sbdy,
-                                                          const float* mean, const float* rstd, const float* gamma,
-                                                          const float* beta, int act, const float* slope,
-                                                          double* partial /* [chunk][G][C][3] */) {
+                                                          NormStat st, const float* gamma, const float* beta, int act,
+                                                          const float* slope, double* bsums) {
   __shared__ double sh[256][3 * VEC];
   const int tid = threadIdx.x, tx = tid % p.cvp, ty = tid / p.cvp;
   const int g = blockIdx.y;
@@ -212,34 +258,45 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int c = tx * VEC + j;
-      mu[j] = mean[g * p.C + c]; rs[j] = rstd[g * p.C + c];
+      norm_mr(st, g * p.C + c, mu[j], rs[j]);
       ga[j] = gamma ? gamma[c] : 1.f; be[j] = gamma ? beta[c] : 0.f;
     }
-    constexpr int BURST = sizeof(T) == 2 ? 8 : 1;
+    // bf16: fp32 partial sums over bursts of 8 rows folded into fp64; fp32: every term straight to fp64 -- see
+    // stats_partial_k.  The loads of a burst (two tensors) are issued together.
+    constexpr int BURST = sizeof(T) == 2 ? 8 : 4;
     RowWalk w(p, r0 + ty);
-    while (w.r < r1) {             // bf16: fp32 bursts of 8 rows folded into fp64 (see stats_partial_k)
+    while (w.r < r1) {
+      float xv[BURST][VEC], dv[BURST][VEC];
+      bool ok[BURST];
+      int64_t lx = w.off(p, g, p.ld, p.sb), ldd = w.off(p, g, lddy, sbdy);
+#pragma unroll
+      for (int u = 0; u < BURST; ++u) {
+        ok[u] = w.r < r1;
+        if (ok[u]) { lx = w.off(p, g, p.ld, p.sb); ldd = w.off(p, g, lddy, sbdy); }
+        vec_io<T, VEC>::load(xb + lx + tx * VEC, xv[u]);
+        vec_io<T, VEC>::load(dyb + ldd + tx * VEC, dv[u]);
+        w.step(p);
+      }
       float f1[VEC], f2[VEC], f3[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { f1[j] = 0.f; f2[j] = 0.f; f3[j] = 0.f; }
 #pragma unroll
       for (int u = 0; u < BURST; ++u) {
-        if (w.r < r1) {
-          float xv[VEC], dv[VEC];
-          vec_io<T, VEC>::load(xb + w.off(p, g, p.ld, p.sb) + tx * VEC, xv);
-          vec_io<T, VEC>::load(dyb + w.off(p, g, lddy, sbdy) + tx * VEC, dv);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            const float xh = (xv[j] - mu[j]) * rs[j];
-            const float z = xh * ga[j] + be[j];
-            float ds; const float da = act_bwd(act, z, a, &ds);
-            const float dz = dv[j] * da;
-            f1[j] += dz; f2[j] = fmaf(dz, xh, f2[j]); f3[j] = fmaf(dv[j], ds, f3[j]);
-          }
-          w.step(p);
+        for (int j = 0; j < VEC; ++j) {
+          const float xh = (xv[u][j] - mu[j]) * rs[j];
+          const float z = xh * ga[j] + be[j];
+          float ds; const float da = act_bwd(act, z, a, &ds);
+          const float dvv = ok[u] ? dv[u][j] : 0.f;
+          const float dz = dvv * da;
+          if (sizeof(T) == 2) { f1[j] += dz; f2[j] = fmaf(dz, xh, f2[j]); f3[j] = fmaf(dvv, ds, f3[j]); }
+          else { s1[j] += (double)dz; s2[j] += (double)(dz * xh); s3[j] += (double)(dvv * ds); }
         }
       }
+      if (sizeof(T) == 2) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { s1[j] += (double)f1[j]; s2[j] += (double)f2[j]; s3[j] += (double)f3[j]; }
+        for (int j = 0; j < VEC; ++j) { s1[j] += (double)f1[j]; s2[j] += (double)f2[j]; s3[j] += (double)f3[j]; }
+      }
     }
   }
 #pragma unroll
@@ -255,59 +312,16 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
   if (ty == 0 && tx < p.cv) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      double* o = partial + (((int64_t)blockIdx.x * p.G + g) * p.C + tx * VEC + j) * 3;
-      o[0] = sh[tid][3 * j]; o[1] = sh[tid][3 * j + 1]; o[2] = sh[tid][3 * j + 2];
+      double* o = bsums + ((int64_t)g * p.C + tx * VEC + j) * 3;
+      add_f64(o, sh[tid][3 * j]); add_f64(o + 1, sh[tid][3 * j + 1]); add_f64(o + 2, sh[tid][3 * j + 2]);
     }
   }
 }
 
-// stage 1: one wave per channel reduces the chunk partials of each of its groups -> tot[(g*C+c)*3 .. +3] (fp64), the fp32
-// means, and dgamma / dbeta[c] = sum over the groups (in group order: the same sum the separate finaliser made)
-__global__ __launch_bounds__(256) void norm_bwd_reduce_k(const double* partial, int nchunks, int G, int C, int64_t R,
-                                                         double* tot, float* sums, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= C) return;
-  double dg = 0.0, db = 0.0;
-  for (int g = 0; g < G; ++g) {
-    const int i = g * C + c;
-    double a = 0.0, b = 0.0, s = 0.0;
-    for (int k = lane; k < nchunks; k += 64) {
-      const double* v = partial + ((int64_t)k * G * C + i) * 3;
-      a += v[0]; b += v[1]; s += v[2];
-    }
-    a = wave_sum(a); b = wave_sum(b); s = wave_sum(s);
-    if (lane == 0) {
-      tot[i * 3] = a; tot[i * 3 + 1] = b; tot[i * 3 + 2] = s;
-      sums[i * 2] = (float)(a / (double)R);
-      sums[i * 2 + 1] = (float)(b / (double)R);
-    }
-    db += a; dg += b;
-  }
-  if (lane == 0) {
-    if (dgamma) dgamma[c] = (float)dg;
-    if (dbeta) dbeta[c] = (float)db;
-  }
-}
-// stage 2: dgamma/dbeta[c] = sum over groups, dslope = sum over everything (<= 1024 numbers)
-__global__ __launch_bounds__(256) void norm_bwd_finalize_k(const double* tot, int G, int C, float* dgamma, float* dbeta,
-                                                           float* dslope) {
-  __shared__ double ssl[256];
-  double sl = 0.0;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    double dg = 0.0, db = 0.0;
-    for (int g = 0; g < G; ++g) { db += tot[(g * C + c) * 3]; dg += tot[(g * C + c) * 3 + 1]; sl += tot[(g * C + c) * 3 + 2]; }
-    if (dgamma) dgamma[c] = (float)dg;
-    if (dbeta) dbeta[c] = (float)db;
-  }
-  ssl[threadIdx.x] = sl;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) ssl[threadIdx.x] += ssl[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0 && dslope) *dslope = (float)ssl[0];
-}
-
+// backward pass 2: dx = rstd * gamma * (dz - mean(dz) - xhat * mean(dz * xhat)); block (0, 0) also writes the parameter
+// gradients dgamma / dbeta[c] = sum over the groups, dslope = sum over everything (<= 1024 numbers)
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p, const float* sums) {
+__global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p) {
   const int b = blockIdx.y;
   const int64_t total = p.V * p.cv;
   const float a = p.slope ? *p.slope : 0.25f;
@@ -315,6 +329,26 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p, const floa
   const T* dyb = reinterpret_cast<const T*>(p.dy) + (int64_t)b * p.sbdy;
   T* ob = reinterpret_cast<T*>(p.y) + (int64_t)b * p.sby;
   const int g = p.inst ? b : 0;
+  const int G = p.inst ? p.B : 1;
+  if (blockIdx.x == 0 && b == 0 && (p.dgamma || p.dbeta || p.dslope)) {
+    __shared__ double ssl[256];
+    double sl = 0.0;
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+      double dg = 0.0, db = 0.0;
+      for (int gg = 0; gg < G; ++gg) {
+        const double* t = p.bsums + ((int64_t)gg * p.C + c) * 3;
+        db += t[0]; dg += t[1]; sl += t[2];
+      }
+      if (p.dgamma) p.dgamma[c] = (float)dg;
+      if (p.dbeta) p.dbeta[c] = (float)db;
+    }
+    if (p.dslope) {
+      ssl[threadIdx.x] = sl;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) ssl[threadIdx.x] += ssl[threadIdx.x + o]; __syncthreads(); }
+      if (threadIdx.x == 0) *p.dslope = (float)ssl[0];
+    }
+  }
   const int64_t stride = (int64_t)gridDim.x * 256, e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (stride % p.cv == 0) {      // fixed channel group per thread: the per-channel constants live in registers
     const int c0 = (int)(e0 % p.cv) * VEC;
@@ -322,15 +356,11 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p, const floa
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int c = c0 + j;
-      rs[j] = p.rstd[g * p.C + c]; mu[j] = p.mean[g * p.C + c];
+      norm_mr(p.st, g * p.C + c, mu[j], rs[j]);
       ga[j] = p.gamma ? p.gamma[c] : 1.f; be[j] = p.gamma ? p.beta[c] : 0.f;
-      s1[j] = sums[(g * p.C + c) * 2]; s2[j] = sums[(g * p.C + c) * 2 + 1];
+      s1[j] = (float)(p.bsums[((int64_t)g * p.C + c) * 3] / p.st.R); s2[j] = (float)(p.bsums[((int64_t)g * p.C + c) * 3 + 1] / p.st.R);
     }
-    const int64_t dvx = stride / p.cv;
-    for (int64_t v = e0 / p.cv; v < p.V; v += dvx) {
-      float xv[VEC], dv[VEC], ov[VEC];
-      vec_io<T, VEC>::load(xb + v * p.ldx + c0, xv);
-      vec_io<T, VEC>::load(dyb + v * p.lddy + c0, dv);
+    auto one = [&](const float* xv, const float* dv, float* ov) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const float xh = (xv[j] - mu[j]) * rs[j];
@@ -339,6 +369,29 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p, const floa
         const float dz = dv[j] * da;
         ov[j] = rs[j] * ga[j] * (dz - s1[j] - xh * s2[j]);
       }
+    };
+    const int64_t dvx = stride / p.cv;
+    int64_t v = e0 / p.cv;
+    constexpr int U = NORM_UNR / 2 > 0 ? NORM_UNR / 2 : 1;       // two tensors are read: half the voxels per trip
+    for (; v + (U - 1) * dvx < p.V; v += U * dvx) {
+      float xv[U][VEC], dv[U][VEC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        vec_io<T, VEC>::load(xb + (v + u * dvx) * p.ldx + c0, xv[u]);
+        vec_io<T, VEC>::load(dyb + (v + u * dvx) * p.lddy + c0, dv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float ov[VEC];
+        one(xv[u], dv[u], ov);
+        vec_io<T, VEC>::store(ob + (v + u * dvx) * p.ldy + c0, ov);
+      }
+    }
+    for (; v < p.V; v += dvx) {
+      float xv[VEC], dv[VEC], ov[VEC];
+      vec_io<T, VEC>::load(xb + v * p.ldx + c0, xv);
+      vec_io<T, VEC>::load(dyb + v * p.lddy + c0, dv);
+      one(xv, dv, ov);
       vec_io<T, VEC>::store(ob + v * p.ldy + c0, ov);
     }
     return;
@@ -351,13 +404,14 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p, const floa
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int c = c0 + j;
-      const float rs = p.rstd[g * p.C + c];
-      const float xh = (xv[j] - p.mean[g * p.C + c]) * rs;
+      float mu, rs; norm_mr(p.st, g * p.C + c, mu, rs);
+      const float xh = (xv[j] - mu) * rs;
       const float ga = p.gamma ? p.gamma[c] : 1.f;
       const float z = p.gamma ? xh * ga + p.beta[c] : xh;
       float ds; const float da = act_bwd(p.act, z, a, &ds);
       const float dz = dv[j] * da;
-      ov[j] = rs * ga * (dz - sums[(g * p.C + c) * 2] - xh * sums[(g * p.C + c) * 2 + 1]);
+      const float s1 = (float)(p.bsums[((int64_t)g * p.C + c) * 3] / p.st.R), s2 = (float)(p.bsums[((int64_t)g * p.C + c) * 3 + 1] / p.st.R);
+      ov[j] = rs * ga * (dz - s1 - xh * s2);
     }
     vec_io<T, VEC>::store(ob + v * p.ldy + c0, ov);
   }
@@ -379,56 +433,41 @@ static int pick_vec(const coma_tensor* x) { return t_vec(x, 4) >= 4 ? 4 : 1; }
 static int pick_vec8(const coma_tensor* x) { return (x->dtype == COMA_BF16 && t_vec(x, 8) == 8) ? 8 : pick_vec(x); }
 
 extern "C" size_t coma_norm_ws_bytes(const coma_tensor* x) {
-  // partials: <= 1024 (chunk,group) pairs x C x 3 doubles, + sums [B][C][2] floats
-  return (size_t)1024 * x->C * 3 * sizeof(double) + (size_t)x->B * x->C * (3 * sizeof(double) + 2 * sizeof(float)) + 256;
+  // column sums (bias gradient, spatial mean): <= 1024 (chunk, group) partial rows of C {sum, sumsq} pairs
+  return (size_t)1024 * x->C * sizeof(double2) + 256;
 }
 
 template <typename T>
-static void launch_partial(const RowsP& p, int vec, double2* partial, hipStream_t s) {
+static void launch_partial(const RowsP& p, int vec, double* sums, double2* partial, hipStream_t s) {
   dim3 grid(p.nchunks, p.G);
-  if (vec == 8) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((stats_partial_k<T, 8>), grid, dim3(256), 0, s, p, partial); }
-  else if (vec == 4) hipLaunchKernelGGL((stats_partial_k<T, 4>), grid, dim3(256), 0, s, p, partial);
-  else hipLaunchKernelGGL((stats_partial_k<T, 1>), grid, dim3(256), 0, s, p, partial);
+  if (vec == 8) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((stats_partial_k<T, 8>), grid, dim3(256), 0, s, p, sums, partial); }
+  else if (vec == 4) hipLaunchKernelGGL((stats_partial_k<T, 4>), grid, dim3(256), 0, s, p, sums, partial);
+  else hipLaunchKernelGGL((stats_partial_k<T, 1>), grid, dim3(256), 0, s, p, sums, partial);
 }
 
-static int run_partial(const coma_tensor* x, int mode, RowsP& p, void* ws, size_t ws_bytes, hipStream_t s) {
-  COMA_CHECK(x && x->data && ws, "norm: null argument");
-  COMA_CHECK(ws_bytes >= coma_norm_ws_bytes(x), "norm: workspace too small (%zu < %zu)", ws_bytes, coma_norm_ws_bytes(x));
+// sums != NULL: atomic adds into the caller's zeroed [G][C][2] record; else per-chunk partial rows in `ws`
+static int run_partial(const coma_tensor* x, int mode, RowsP& p, double* sums, void* ws, size_t ws_bytes, hipStream_t s) {
+  COMA_CHECK(x && x->data && (sums || ws), "norm: null argument");
+  COMA_CHECK(sums || ws_bytes >= coma_norm_ws_bytes(x), "norm: workspace too small (%zu < %zu)", ws_bytes, coma_norm_ws_bytes(x));
   const int vec = pick_vec8(x);
   p = make_rows(x, mode, vec);
   COMA_CHECK(p.cv <= 256, "norm: C=%d too large", x->C);
-  if (x->dtype == COMA_F32) launch_partial<float>(p, vec, (double2*)ws, s);
-  else launch_partial<bf16_t>(p, vec, (double2*)ws, s);
+  if (x->dtype == COMA_F32) launch_partial<float>(p, vec, sums, (double2*)ws, s);
+  else launch_partial<bf16_t>(p, vec, sums, (double2*)ws, s);
   COMA_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int coma_norm_stats(const coma_tensor* x, int32_t mode, float eps, float* mean, float* rstd,
-                               float* running_mean, float* running_var, float momentum, void* ws,
-                               size_t ws_bytes, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+extern "C" int coma_norm_stats(const coma_tensor* x, int32_t mode, double* sums, void* stream) {
+  COMA_CHECK(sums, "norm_stats: null sums record");
   RowsP p;
-  if (int rc = run_partial(x, mode, p, ws, ws_bytes, s)) return rc;
-  const int n = p.G * p.C;
-  hipLaunchKernelGGL(stats_finalize_k, dim3((n + 3) / 4), dim3(256), 0, s, (const double2*)ws, p.nchunks, p.G,
-                     p.C, p.R, eps, mean, rstd, running_mean, running_var, momentum);
-  COMA_LAUNCH_CHECK();
-  return 0;
-}
-
-int norm_stats_finalize(const double2* partial, int nchunks, int G, int C, int64_t R, float eps, float* mean, float* rstd,
-                        float* running_mean, float* running_var, float momentum, hipStream_t s) {
-  const int n = G * C;
-  hipLaunchKernelGGL(stats_finalize_k, dim3((n + 3) / 4), dim3(256), 0, s, partial, nchunks, G, C, R, eps, mean, rstd,
-                     running_mean, running_var, momentum);
-  COMA_LAUNCH_CHECK();
-  return 0;
+  return run_partial(x, mode, p, sums, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int coma_spatial_mean(const coma_tensor* x, float* out, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   RowsP p;
-  if (int rc = run_partial(x, COMA_NORM_INSTANCE, p, ws, ws_bytes, s)) return rc;
+  if (int rc = run_partial(x, COMA_NORM_INSTANCE, p, nullptr, ws, ws_bytes, s)) return rc;
   const int n = p.G * p.C;
   hipLaunchKernelGGL(colsum_finalize_k, dim3((n + 3) / 4), dim3(256), 0, s, (const double2*)ws, p.nchunks, p.G,
                      p.C, 1.0 / (double)p.R, out);
@@ -439,7 +478,7 @@ extern "C" int coma_spatial_mean(const coma_tensor* x, float* out, void* ws, siz
 // used by coma_conv_wgrad for the bias gradient: out[B or 1][C] = sum over voxels (and batch)
 int colsum(const coma_tensor* x, int per_sample, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
   RowsP p;
-  if (int rc = run_partial(x, per_sample ? COMA_NORM_INSTANCE : COMA_NORM_BATCH, p, ws, ws_bytes, s)) return rc;
+  if (int rc = run_partial(x, per_sample ? COMA_NORM_INSTANCE : COMA_NORM_BATCH, p, nullptr, ws, ws_bytes, s)) return rc;
   const int n = p.G * p.C;
   hipLaunchKernelGGL(colsum_finalize_k, dim3((n + 3) / 4), dim3(256), 0, s, (const double2*)ws, p.nchunks, p.G,
                      p.C, 1.0, out);
@@ -453,26 +492,44 @@ static ApplyP make_apply(const coma_tensor* x, const coma_tensor* y, int mode, i
   p.y = y->data; p.ldy = y->ld; p.sby = y->sb;
   p.dy = nullptr; p.lddy = 0; p.sbdy = 0;
   p.V = t_vox(x); p.B = x->B; p.C = x->C; p.cv = x->C / vec; p.inst = mode == COMA_NORM_INSTANCE;
+  p.rmean = p.rvar = nullptr; p.momentum = 0.f; p.bsums = nullptr; p.dgamma = p.dbeta = p.dslope = nullptr;
   return p;
 }
 
-static unsigned ew_blocks(int64_t total) {
-  int64_t nb = (total + 255) / 256;
+static NormStat make_stat(const coma_tensor* x, int mode, const double* sums, float eps, const float* mean, const float* rstd) {
+  NormStat st;
+  st.sums = sums; st.eps = eps; st.mean = mean; st.rstd = rstd;
+  st.R = (double)(mode == COMA_NORM_INSTANCE ? t_vox(x) : t_vox(x) * x->B);
+  return st;
+}
+
+static unsigned ew_blocks(int64_t total, int per_thread) {
+  int64_t nb = (total + 256 * (int64_t)per_thread - 1) / (256 * (int64_t)per_thread);
   if (nb > 4096) nb = 4096;
   return (unsigned)(nb < 1 ? 1 : nb);
 }
+// the apply kernels keep a thread on ONE channel group when the grid stride is a multiple of the groups per voxel
+static unsigned apply_blocks(int64_t total, int cv, int per_thread) {
+  unsigned nb = ew_blocks(total, per_thread);
+  if (cv > 0 && cv <= 256 && (256 % cv) == 0) return nb;                    // 256 % cv == 0: any block count works
+  while (nb > 1 && ((int64_t)nb * 256) % cv != 0) --nb;
+  return nb;
+}
 
-extern "C" int coma_norm_act_fwd(const coma_tensor* x, int32_t mode, const float* mean, const float* rstd,
-                                 const float* gamma, const float* beta, int32_t act, const float* slope,
-                                 const coma_tensor* y, void* stream) {
+extern "C" int coma_norm_act_fwd(const coma_tensor* x, int32_t mode, const double* sums, float eps, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, int32_t act, const float* slope,
+                                 float* running_mean, float* running_var, float momentum, const coma_tensor* y, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  COMA_CHECK(x && y && x->data && y->data && mean && rstd, "norm_act_fwd: null argument");
+  COMA_CHECK(x && y && x->data && y->data && (sums || (mean && rstd)), "norm_act_fwd: null argument");
   COMA_CHECK(t_same_grid(x, y) && x->C == y->C && x->dtype == y->dtype, "norm_act_fwd: shape/dtype mismatch");
+  COMA_CHECK(!running_mean || (sums && running_var && mode == COMA_NORM_BATCH), "norm_act_fwd: running statistics need a BatchNorm sums record");
   int vec = (pick_vec(x) == 4 && pick_vec(y) == 4) ? 4 : 1;
   if (x->dtype == COMA_BF16 && t_vec(x, 8) == 8 && t_vec(y, 8) == 8) vec = 8;     // 16 bytes per lane
   ApplyP p = make_apply(x, y, mode, vec);
-  p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.slope = slope; p.act = act;
-  dim3 grid(ew_blocks(p.V * p.cv), x->B);
+  p.st = make_stat(x, mode, sums, eps, mean, rstd);
+  p.gamma = gamma; p.beta = beta; p.slope = slope; p.act = act;
+  p.rmean = running_mean; p.rvar = running_var; p.momentum = momentum;
+  dim3 grid(apply_blocks(p.V * p.cv, p.cv, NORM_UNR), x->B);
 #define L(T, V) hipLaunchKernelGGL((norm_act_fwd_k<T, V>), grid, dim3(256), 0, s, p)
   if (x->dtype == COMA_F32) { if (vec == 4) L(float, 4); else L(float, 1); }
   else { if (vec == 8) L(bf16_t, 8); else if (vec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
@@ -481,43 +538,35 @@ extern "C" int coma_norm_act_fwd(const coma_tensor* x, int32_t mode, const float
   return 0;
 }
 
-extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, int32_t mode, const float* mean,
-                                 const float* rstd, const float* gamma, const float* beta, int32_t act,
-                                 const float* slope, const coma_tensor* dx, float* dgamma, float* dbeta,
-                                 float* dslope, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, int32_t mode, const double* sums, float eps,
+                                 const float* gamma, const float* beta, int32_t act, const float* slope,
+                                 const coma_tensor* dx, float* dgamma, float* dbeta, float* dslope, double* bsums,
+                                 void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  COMA_CHECK(x && dy && dx && x->data && dy->data && dx->data && mean && rstd && ws, "norm_act_bwd: null argument");
+  COMA_CHECK(x && dy && dx && x->data && dy->data && dx->data && sums && bsums, "norm_act_bwd: null argument");
   COMA_CHECK(t_same_grid(x, dy) && t_same_grid(x, dx) && x->C == dy->C && x->C == dx->C, "norm_act_bwd: shape mismatch");
   COMA_CHECK(x->dtype == dy->dtype && x->dtype == dx->dtype, "norm_act_bwd: dtype mismatch");
-  COMA_CHECK(ws_bytes >= coma_norm_ws_bytes(x), "norm_act_bwd: workspace too small");
   const int vec = (pick_vec(x) == 4 && pick_vec(dy) == 4 && pick_vec(dx) == 4) ? 4 : 1;
   const int pvec = vec;     // (8-wide measured slower here: 24 fp64 accumulators per lane, 48 KB of LDS)
   RowsP rp = make_rows(x, mode, pvec);
   COMA_CHECK(rp.cv <= 256, "norm: C=%d too large", x->C);
-  double* partial = (double*)ws;
-  double* tot = (double*)((char*)ws + (size_t)1024 * x->C * 3 * sizeof(double));
-  float* sums = (float*)(tot + (size_t)x->B * x->C * 3);
+  const NormStat st = make_stat(x, mode, sums, eps, nullptr, nullptr);
   dim3 pg(rp.nchunks, rp.G);
 #define L(T, V) hipLaunchKernelGGL((norm_bwd_partial_k<T, V>), pg, dim3(256), 0, s, rp, dy->data, dy->ld, dy->sb, \
-                                   mean, rstd, gamma, beta, act, slope, partial)
+                                   st, gamma, beta, act, slope, bsums)
   if (x->dtype == COMA_F32) { if (pvec == 4) L(float, 4); else L(float, 1); }
-  else { if (pvec == 8) L(bf16_t, 8); else if (pvec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
+  else { if (pvec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
 #undef L
   COMA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_bwd_reduce_k, dim3((rp.C + 3) / 4), dim3(256), 0, s, partial, rp.nchunks, rp.G, rp.C,
-                     rp.R, tot, sums, dgamma, dbeta);
-  COMA_LAUNCH_CHECK();
-  if (dslope) {          // the PReLU slope is one number summed over every (group, channel): its own small launch
-    hipLaunchKernelGGL(norm_bwd_finalize_k, dim3(1), dim3(256), 0, s, tot, rp.G, rp.C, (float*)nullptr, (float*)nullptr, dslope);
-    COMA_LAUNCH_CHECK();
-  }
   int avec = vec;
   if (x->dtype == COMA_BF16 && t_vec(x, 8) == 8 && t_vec(dy, 8) == 8 && t_vec(dx, 8) == 8) avec = 8;
   ApplyP p = make_apply(x, dx, mode, avec);
   p.dy = dy->data; p.lddy = dy->ld; p.sbdy = dy->sb;
-  p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.slope = slope; p.act = act;
-  dim3 grid(ew_blocks(p.V * p.cv), x->B);
-#define L(T, V) hipLaunchKernelGGL((norm_act_bwd_apply_k<T, V>), grid, dim3(256), 0, s, p, sums)
+  p.st = st;
+  p.gamma = gamma; p.beta = beta; p.slope = slope; p.act = act;
+  p.bsums = bsums; p.dgamma = dgamma; p.dbeta = dbeta; p.dslope = dslope;
+  dim3 grid(apply_blocks(p.V * p.cv, p.cv, NORM_UNR / 2), x->B);
+#define L(T, V) hipLaunchKernelGGL((norm_act_bwd_apply_k<T, V>), grid, dim3(256), 0, s, p)
   if (x->dtype == COMA_F32) { if (avec == 4) L(float, 4); else L(float, 1); }
   else { if (avec == 8) L(bf16_t, 8); else if (avec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
 #undef L

@@ -208,12 +208,12 @@ __global__ __launch_bounds__(256) void weight_prep_bwd_k(const float* dwk, const
 
 extern "C" int coma_weight_prep_bwd(const float* dwk, const float* master, const float* r, int32_t E, int32_t Bw, int32_t N,
                                     int32_t C, int32_t taps, int64_t se, int64_t sn, int64_t sc, float* dmaster, float* dr,
-                                    void* stream) {
+                                    int32_t zeroed, void* stream) {
   COMA_CHECK(dwk && master && dmaster, "weight_prep_bwd: null argument");
   COMA_CHECK(taps == 27 || taps == 1, "weight_prep_bwd: taps=%d unsupported", taps);
   COMA_CHECK(Bw >= 1 && Bw <= 8 && (!dr || Bw * E <= 64), "weight_prep_bwd: Bw=%d E=%d out of range (Bw 1..8, Bw*E <= 64)", Bw, E);
   hipStream_t s = (hipStream_t)stream;
-  if (dr && hipMemsetAsync(dr, 0, sizeof(float) * Bw * E, s) != hipSuccess) { coma_set_error("weight_prep_bwd: memset failed"); return 2; }
+  if (dr && !(zeroed & COMA_ZEROED_OUT) && hipMemsetAsync(dr, 0, sizeof(float) * Bw * E, s) != hipSuccess) { coma_set_error("weight_prep_bwd: memset failed"); return 2; }
   dim3 grid((unsigned)(((int64_t)N * C + 255) / 256));
 #define L(TP, BBV) hipLaunchKernelGGL((weight_prep_bwd_k<TP, BBV>), grid, dim3(256), 0, s, dwk, master, r, E, Bw, N, C, se, sn, sc, dmaster, dr)
   if (taps == 27) { if (Bw <= 2) L(27, 2); else if (Bw <= 4) L(27, 4); else L(27, 8); }

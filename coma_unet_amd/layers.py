@@ -90,8 +90,8 @@ def _norm_params(cfg, bn, training):
 
 
 def norm_act(cfg, x, bn, mode, act, slope, training, out=None, pre=None):
-    gamma, beta, rmean, rvar, momentum, eps = _norm_params(cfg, bn, training) if pre is None else \
-        ((bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.1, bn.eps) if bn is not None else (None,) * 4 + (0.1, 1e-5))
+    """`pre`: the statistics record the convolution that wrote `x` produced (ops.ConvLayer with norm=mode)."""
+    gamma, beta, rmean, rvar, momentum, eps = _norm_params(cfg, bn, training)
     return ops.NormAct.apply(x, gamma, beta, slope, rmean, rvar, mode, act, momentum, eps, training,
                              Out(out) if out is not None else None, pre)
 
@@ -102,10 +102,8 @@ def conv_norm_act(cfg, x, conv_fn, adn, out=None):
     slope = adn.A.weight if adn.act_name in ("prelu", "prelu_relu") else None
     if adn.mode == L.NORM_BATCH and not adn.training:     # eval: running statistics, plain conv
         return norm_act(cfg, conv_fn(None), bn, adn.mode, _ACTS[adn.act_name], slope, False, out)
-    _g, _b, rmean, rvar, momentum, eps = _norm_params(cfg, bn, adn.training)
-    upd = adn.training and bn is not None
-    y, mean, rstd = conv_fn((adn.mode, eps, rmean if upd else None, rvar if upd else None, momentum))
-    return norm_act(cfg, y, bn, adn.mode, _ACTS[adn.act_name], slope, adn.training, out, pre=(mean, rstd))
+    y, sums = conv_fn(adn.mode)
+    return norm_act(cfg, y, bn, adn.mode, _ACTS[adn.act_name], slope, adn.training, out, pre=sums)
 
 
 def conv_then_bn(cfg, x, cv, bn, act, training, out=None):
@@ -114,9 +112,8 @@ def conv_then_bn(cfg, x, cv, bn, act, training, out=None):
     and the convolution's bias -- removed again by the BatchNorm -- gets its exact zero gradient."""
     if not training:
         return norm_act(cfg, cv(x), bn, L.NORM_BATCH, act, None, False, out)
-    _g, _b, rmean, rvar, momentum, eps = _norm_params(cfg, bn, True)
-    y, mean, rstd = conv_plain(cfg, x, cv.conv, cv.k, cv.s, cv.transposed, None, (L.NORM_BATCH, eps, rmean, rvar, momentum))
-    return norm_act(cfg, y, bn, L.NORM_BATCH, act, None, True, out, pre=(mean, rstd))
+    y, sums = conv_plain(cfg, x, cv.conv, cv.k, cv.s, cv.transposed, None, L.NORM_BATCH)
+    return norm_act(cfg, y, bn, L.NORM_BATCH, act, None, True, out, pre=sums)
 
 
 def conv_plain(cfg, x, conv: nn.Module, ksize, stride, transposed, out=None, norm=None):

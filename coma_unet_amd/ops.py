@@ -109,6 +109,84 @@ def _f32(n, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+class ZeroArena:
+    """ONE zeroed device buffer per step for everything the kernels merge into with atomics: the fp64 statistics records
+    of the normalisations (forward {sum, sumsq}, backward partial sums), the kernel-layout weight gradients, their
+    replica / split-K scratch and the routing gradients.  ``FusedAdamW.zero_grad()`` arms it, every taker gets a private
+    slice that is all zeros, and ``FusedAdamW.step()`` (after backward: every slice is dead by then) clears what the
+    step dirtied with ONE memset -- instead of ~60 memset nodes and ~95 finalise launches per step.  Invariant: outside
+    [0, cur) the buffer is zero.  Not armed (op tests, inference): ``take`` returns None and callers fall back to
+    ``torch.zeros`` / the library's own memsets.  The clearing memset sits at the END of the step so that a step
+    captured into a hipGraph clears exactly what it dirtied, whatever ran before the capture."""
+    _arenas = {}
+    nbytes = int(os.environ.get("COMA_ZERO_ARENA_MB", "1024")) << 20
+    enabled = os.environ.get("COMA_ZERO_ARENA", "1") not in ("0", "")
+
+    def __init__(self, device):
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.cur = 0
+        self.armed = False
+        self.missed = 0          # bytes requests that did not fit (diagnostic)
+
+    @classmethod
+    def get(cls, device):
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        a = cls._arenas.get(key)
+        if a is None:
+            a = cls._arenas[key] = ZeroArena(torch.device("cuda", key))
+        return a
+
+    @classmethod
+    def begin_step(cls, device=None):
+        if not cls.enabled or not torch.cuda.is_available():
+            return
+        a = cls.get(device if device is not None else torch.cuda.current_device())
+        a.clean()                # (a step that died half-way, or forward passes outside a step)
+        a.armed = True
+
+    @classmethod
+    def end_step(cls):
+        for a in cls._arenas.values():
+            a.clean()
+            a.armed = False
+
+    def clean(self):
+        if self.cur:
+            self.buf[:self.cur].zero_()
+            self.cur = 0
+
+    @classmethod
+    def take(cls, nbytes, device, dtype=torch.uint8):
+        """A zeroed 1-d tensor of `nbytes` bytes viewed as `dtype`, or None when the arena is not armed / exhausted."""
+        if not cls.enabled:
+            return None
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        a = cls._arenas.get(key)
+        if a is None or not a.armed:
+            return None
+        n = (int(nbytes) + 255) & ~255
+        if a.cur + n > a.buf.numel():
+            a.missed += n
+            return None
+        t = a.buf[a.cur:a.cur + int(nbytes)]
+        a.cur += n
+        return t if dtype == torch.uint8 else t.view(dtype)
+
+
+def _zeros_f64(n, device):
+    """A zeroed fp64 record (statistics of one normalisation): arena slice, else a fresh torch.zeros."""
+    t = ZeroArena.take(8 * n, device, torch.float64)
+    return t if t is not None else torch.zeros(n, dtype=torch.float64, device=device)
+
+
+def stats_from_sums(sums, count, eps):
+    """(mean, rstd) fp32 of a statistics record [G, C, 2] = {sum, sumsq} -- what every kernel derives on the fly
+    (csrc/norm.hip, NormStat); host-side twin for tests and diagnostics."""
+    m = sums[..., 0] / count
+    var = (sums[..., 1] / count - m * m).clamp_min(0.0)
+    return m.float(), (1.0 / torch.sqrt(var + eps)).float()
+
+
 class GradSink:
     """Write-through parameter gradients.  ``FusedAdamW(write_through=True)`` marks every parameter whose
     ``.grad`` is a slot of its flat gradient buffer; the backward kernels then write that slot directly ("=")
@@ -123,6 +201,7 @@ class GradSink:
         cls.written.clear()
         SidePrep.join()
         SidePrep._live = 0
+        ZeroArena.begin_step()
 
     @classmethod
     def slots(cls, params):
@@ -272,9 +351,15 @@ def _prep_bwd(dwk, master, rr, meta, p_master):
     has_e, E, Bw, cout, cin, taps, se, sn_f, sc_f = meta
     sink = GradSink.slot(p_master)
     dmaster = sink if sink is not None else torch.empty_like(master)
-    dr = _f32((Bw, E), master.device) if has_e else None
+    dr, zeroed = None, 0
+    if has_e:
+        dr = ZeroArena.take(4 * Bw * E, master.device, torch.float32)
+        if dr is not None:
+            dr, zeroed = dr.view(Bw, E), L.ZEROED_OUT
+        else:
+            dr = _f32((Bw, E), master.device)
     check(lib.coma_weight_prep_bwd(ptr(dwk), ptr(master), ptr(rr), E, Bw, cout, cin, taps, se, sn_f, sc_f,
-                                   ptr(dmaster), ptr(dr), L.stream()), "coma_weight_prep_bwd")
+                                   ptr(dmaster), ptr(dr), zeroed, L.stream()), "coma_weight_prep_bwd")
     return (None if sink is not None else dmaster), dr
 
 
@@ -369,8 +454,20 @@ def pick_algo(x_shape, x_dtype, n_out, ksize, stride, transposed, per_sample, de
     return a_f, a_d
 
 
+def _scratch(nbytes, device):
+    """(buffer, zeroed flag): the convolution's scratch as a private zeroed arena slice when the step's arena is armed
+    (the library then skips its memset), else the shared stream-ordered workspace."""
+    if nbytes > 0:
+        z = ZeroArena.take(nbytes, device)
+        if z is not None:
+            return z, L.ZEROED_WS
+    return workspace(nbytes, device), 0
+
+
 def _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm):
-    """One forward launch; with `norm` the (mean, rstd) of the normalisation that follows come out of the same pass."""
+    """One forward launch; with `norm` (the mode of the normalisation that follows: L.NORM_BATCH / L.NORM_INSTANCE, or a
+    tuple starting with it) its fp64 statistics record sums[G, C, 2] = {sum, sumsq} comes out of the same pass:
+    returns (y, sums) then, else (y, None)."""
     B, Do, Ho, Wo = conv_out_grid(x.shape, ksize, stride, form == 1)
     n = wk_f.shape[2]
     y = out.t if out is not None else _new((B, Do, Ho, Wo, n), x.dtype, x.device)
@@ -379,22 +476,20 @@ def _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm):
     tag = (tuple(x.shape), n, ksize, stride, form)
     cx, cy = ct(x), ct(y)
     kind = conv_class(_ALGO_NAMES[lib.coma_conv_pick_algo(d, cx, cy)] if KernelTimer.enabled else "", x.shape[4], n)
+    ws, zf = _scratch(lib.coma_conv_fwd_ws_bytes(d, cx, cy), x.device)      # split-K scratch of the deep layers
     if norm is None:
-        ws = workspace(lib.coma_conv_fwd_ws_bytes(d, cx, cy), x.device)      # split-K scratch of the deep layers
         KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
                         lambda: check(lib.coma_conv_fwd_ws(d, cx, ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), cy, ptr(ws),
-                                                           ws.numel(), L.stream()), "coma_conv_fwd"), tag=tag)
-        return y, None, None
-    mode, eps, rmean, rvar, momentum = norm
+                                                           ws.numel(), zf, L.stream()), "coma_conv_fwd"), tag=tag)
+        return y, None
+    mode = norm[0] if isinstance(norm, (tuple, list)) else norm
     G = B if mode == L.NORM_INSTANCE else 1
-    mean, rstd = _f32((G, n), x.device), _f32((G, n), x.device)
-    ws = workspace(max(lib.coma_norm_ws_bytes(cy), lib.coma_conv_fwd_ws_bytes(d, cx, cy)), x.device)
+    sums = _zeros_f64(G * n * 2, x.device).view(G, n, 2)
     KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
                     lambda: check(lib.coma_conv_fwd_norm_stats(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), cy,
-                                                               mode, eps, ptr(mean), ptr(rstd), ptr(rmean), ptr(rvar),
-                                                               momentum, ptr(ws), ws.numel(), L.stream()),
+                                                               mode, ptr(sums), ptr(ws), ws.numel(), zf, L.stream()),
                                   "coma_conv_fwd_norm_stats"), tag=tag)
-    return y, mean, rstd
+    return y, sums
 
 
 def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_dx, need_dw, bias_mode, p_bias):
@@ -408,17 +503,26 @@ def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_d
         assert wk_d is not None, "data gradient requested but dgrad weights were not prepared"
         dx = _new(x.shape, x.dtype, x.device)
         dd, cdy_, cdx = _desc(ksize, stride, 1 - form, per_sample, algo), ct(dy), ct(dx)
-        wsd = workspace(lib.coma_conv_fwd_ws_bytes(dd, cdy_, cdx), x.device)
+        wsd, zfd = _scratch(lib.coma_conv_fwd_ws_bytes(dd, cdy_, cdx), x.device)
         KernelTimer.run("conv_dgrad", conv_class(_ALGO_NAMES[lib.coma_conv_pick_algo(dd, cdy_, cdx)] if KernelTimer.enabled else "",
                                                    dy.shape[4], x.shape[4]),
                         conv_flops(dy.shape, dx.shape, ksize, stride),
                         lambda: check(lib.coma_conv_fwd_ws(dd, cdy_, ptr(wk_d), L.dtype_code(wk_d.dtype), None, cdx, ptr(wsd),
-                                                           wsd.numel(), s), "coma_conv_fwd(dgrad)"), tag=tag)
+                                                           wsd.numel(), zfd, s), "coma_conv_fwd(dgrad)"), tag=tag)
     if need_dw:
         d = _desc(ksize, stride, form, per_sample, algo)
         cx, cdy = ct(x), ct(dy)
-        ws = workspace(lib.coma_conv_wgrad_ws_bytes(d, cx, cdy), x.device)
-        dwk = _f32(wshape, x.device)
+        nws = lib.coma_conv_wgrad_ws_bytes(d, cx, cdy)
+        # a bias reduction writes its partial rows into the scratch first: shared workspace then (nothing pre-zeroed)
+        ws, zf = _scratch(nws, x.device) if bias_mode != 1 else (workspace(nws, x.device), 0)
+        nel = 1
+        for k_ in wshape:
+            nel *= k_
+        dwk = ZeroArena.take(4 * nel, x.device, torch.float32)
+        if dwk is not None:
+            dwk, zf = dwk.view(wshape), zf | L.ZEROED_OUT
+        else:
+            dwk = _f32(wshape, x.device)
         bshape = (x.shape[0], wshape[2]) if per_sample else (wshape[2],)
         dbias_k = None
         if bias_mode == 1:
@@ -430,29 +534,28 @@ def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_d
             dbias = None if sink is not None else torch.zeros(bshape, dtype=torch.float32, device=x.device)
         walgo = conv_class(_ALGO_NAMES[lib.coma_conv_wgrad_algo(d, cx, cdy)] if KernelTimer.enabled else "", x.shape[4], dy.shape[4])
         KernelTimer.run("conv_wgrad", walgo, conv_flops(x.shape, dy.shape, ksize, stride),
-                        lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias_k), ptr(ws), ws.numel(), s),
+                        lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias_k), ptr(ws), ws.numel(), zf, s),
                                       "coma_conv_wgrad"), tag=tag)
     return dx, dwk, dbias
 
 
 class Conv(Function):
-    """y = conv(x) on prepared kernel-layout weights (stand-alone form, used by the op tests).  With `norm` =
-    (mode, eps, running_mean, running_var, momentum) the statistics of the BatchNorm(train)/InstanceNorm that
-    follows are produced in the same pass (epilogue-fused where the kernel supports it) and returned as
-    (y, mean, rstd)."""
+    """y = conv(x) on prepared kernel-layout weights (stand-alone form, used by the op tests).  With `norm` = the mode
+    of the BatchNorm(train)/InstanceNorm that follows, its statistics record is produced in the same pass
+    (epilogue-fused where the kernel supports it): returns (y, sums[G, C, 2])."""
 
     @staticmethod
     def forward(ctx, x, wk_f, wk_d, bias, ksize, stride, transposed, per_sample, algo, out, norm=None):
         ctx.set_materialize_grads(False)
         ctx.p_bias = bias if not per_sample else None
         form = 1 if transposed else 0
-        y, mean, rstd = _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm)
+        y, sums = _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm)
         ctx.save_for_backward(x, wk_d)
         ctx.meta = (ksize, stride, form, per_sample, algo, bias is not None, tuple(wk_f.shape))
         if norm is None:
             return y
-        ctx.mark_non_differentiable(mean, rstd)
-        return y, mean, rstd
+        ctx.mark_non_differentiable(sums)
+        return y, sums
 
     @staticmethod
     def backward(ctx, dy, *_unused):
@@ -493,20 +596,20 @@ class ConvLayer(Function):
             if SidePrep._on:
                 SidePrep.fence(x.device)      # (routing / bias mix of this layer were queued on the side stream)
             wk_f, wk_d, rr, pmeta = _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype)
-        y, mean, rstd = _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm)
+        y, sums = _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm)
         ctx.save_for_backward(x, wk_d, master, rr)
         ctx.side = side
         if side and any(ctx.needs_input_grad):
             SidePrep._live += 1
         ctx.p_master, ctx.p_bias = master, (bias if not per_sample else None)
         # per-sample biases survive a BATCH norm (only their batch mean is removed); an instance norm removes them
-        removed = norm is not None and (not per_sample or norm[0] == L.NORM_INSTANCE)
+        removed = norm is not None and (not per_sample or (norm[0] if isinstance(norm, (tuple, list)) else norm) == L.NORM_INSTANCE)
         bias_mode = 0 if bias is None else (2 if (bias_zero_grad and removed) else 1)
         ctx.meta = (ksize, stride, form, per_sample, algo, bias_mode, tuple(wk_f.shape), pmeta)
         if norm is None:
             return y
-        ctx.mark_non_differentiable(mean, rstd)
-        return y, mean, rstd
+        ctx.mark_non_differentiable(sums)
+        return y, sums
 
     @staticmethod
     def backward(ctx, dy, *_unused):
@@ -539,6 +642,10 @@ class ConvLayer(Function):
 # BatchNorm (train) / InstanceNorm + activation
 # --------------------------------------------------------------------------------------
 class NormAct(Function):
+    """BatchNorm3d(train / eval) or InstanceNorm3d + activation.  `pre`: the fp64 statistics record sums[G, C, 2] the
+    convolution that wrote `x` already produced; else the record is made here by one statistics pass.  The kernels
+    derive mean / rstd from the record themselves; the forward apply also moves BatchNorm's running statistics."""
+
     @staticmethod
     def forward(ctx, x, gamma, beta, slope, rmean, rvar, mode, act, momentum, eps, training, out, pre=None):
         ctx.params = (gamma, beta, slope)
@@ -548,41 +655,41 @@ class NormAct(Function):
         cx = ct(x)
         s = L.stream()
         use_batch_stats = training or mode == L.NORM_INSTANCE
+        sums = mean = rstd = None
         if pre is not None:          # statistics already produced by the conv that wrote x
-            mean, rstd = pre
+            sums = pre
         elif use_batch_stats:
-            mean, rstd = _f32((G, C), dev), _f32((G, C), dev)
-            ws = workspace(lib.coma_norm_ws_bytes(cx), dev)
-            upd = rmean is not None and training
-            check(lib.coma_norm_stats(cx, mode, eps, ptr(mean), ptr(rstd), ptr(rmean) if upd else None,
-                                      ptr(rvar) if upd else None, momentum, ptr(ws), ws.numel(), s), "coma_norm_stats")
+            sums = _zeros_f64(G * C * 2, dev).view(G, C, 2)
+            check(lib.coma_norm_stats(cx, mode, ptr(sums), s), "coma_norm_stats")
         else:
             mean = rmean.reshape(1, C).float().contiguous()
             rstd = torch.rsqrt(rvar.reshape(1, C).float() + eps).contiguous()
+        upd = sums is not None and rmean is not None and training and mode == L.NORM_BATCH
         y = out.t if out is not None else _new(x.shape, x.dtype, dev)
-        check(lib.coma_norm_act_fwd(cx, mode, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(slope), ct(y), s),
+        check(lib.coma_norm_act_fwd(cx, mode, ptr(sums), eps, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(slope),
+                                    ptr(rmean) if upd else None, ptr(rvar) if upd else None, momentum, ct(y), s),
               "coma_norm_act_fwd")
-        ctx.save_for_backward(x, mean, rstd, gamma, beta, slope)
-        ctx.meta = (mode, act, use_batch_stats)
+        ctx.save_for_backward(x, sums, gamma, beta, slope)
+        ctx.meta = (mode, act, use_batch_stats, eps)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, mean, rstd, gamma, beta, slope = ctx.saved_tensors
-        mode, act, use_batch_stats = ctx.meta
+        x, sums, gamma, beta, slope = ctx.saved_tensors
+        mode, act, use_batch_stats, eps = ctx.meta
         if not use_batch_stats:
             raise RuntimeError("backward through eval-mode BatchNorm is not part of the training path")
         dev = x.device
-        C = x.shape[4]
+        B, C = x.shape[0], x.shape[4]
+        G = B if mode == L.NORM_INSTANCE else 1
         dx = _new(x.shape, x.dtype, dev)
         sinks = GradSink.slots(ctx.params)      # one kernel chain writes all three: one flush, then three marks
         dgamma = sinks[0] if sinks[0] is not None else (_f32(C, dev) if gamma is not None else None)
         dbeta = sinks[1] if sinks[1] is not None else (_f32(C, dev) if beta is not None else None)
         dslope = sinks[2] if sinks[2] is not None else (_f32(1, dev) if slope is not None else None)
-        cx = ct(x)
-        ws = workspace(lib.coma_norm_ws_bytes(cx), dev)
-        check(lib.coma_norm_act_bwd(cx, ct(dy), mode, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(slope),
-                                    ct(dx), ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(ws), ws.numel(), L.stream()),
+        bsums = _zeros_f64(G * C * 3, dev)
+        check(lib.coma_norm_act_bwd(ct(x), ct(dy), mode, ptr(sums), eps, ptr(gamma), ptr(beta), act, ptr(slope),
+                                    ct(dx), ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(bsums), L.stream()),
               "coma_norm_act_bwd")
         return (dx, None if sinks[0] is not None else dgamma, None if sinks[1] is not None else dbeta,
                 None if sinks[2] is not None else dslope, None, None, None, None, None, None, None, None, None)

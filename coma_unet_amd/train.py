@@ -119,6 +119,7 @@ class GraphedTrainStep:
                 self.losses, self.outputs = forward_loss(model, criterion, self.batch)
                 self.losses[0].backward()
                 ops.SidePrep.join()
+                ops.ZeroArena.end_step()      # the clearing memset of the step's zeroed arena belongs INSIDE the replayed part
         if reducer is None or self.in_graph:
             # capture executes nothing: undo the host-side step count train_step's optimizer.step() just added
             optimizer._flat_step -= 1

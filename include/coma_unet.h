@@ -35,12 +35,22 @@
 extern "C" {
 #endif
 
-/* 2 (round 3): coma_conv_pick_algo / coma_conv_wgrad_algo may answer 3 (fp32 MFMA), algo 0 routes fp32 tensors to the
+/* 2 (round 2): coma_conv_pick_algo / coma_conv_wgrad_algo may answer 3 (fp32 MFMA), algo 0 routes fp32 tensors to the
  * fp32 MFMA kernels and one-channel 1x1x1 layers to conv_point1 (fp32 kernel-layout weights) before the bf16 MFMA path;
- * new exports coma_last_kernel, coma_comm_*, coma_allreduce/reduce_scatter/allgather/broadcast. */
-#define COMA_ABI_VERSION 2
+ * new exports coma_last_kernel, coma_comm_*, coma_allreduce/reduce_scatter/allgather/broadcast.
+ * 3 (round 3): normalisation statistics travel as caller-zeroed fp64 records (coma_norm_stats / coma_norm_act_fwd /
+ * coma_norm_act_bwd / coma_conv_fwd_norm_stats: no mean / rstd tensors, no finalise launches); `zeroed` arguments on
+ * coma_conv_fwd_ws / coma_conv_fwd_norm_stats / coma_conv_wgrad / coma_weight_prep_bwd. */
+#define COMA_ABI_VERSION 3
 
 enum { COMA_F32 = 0, COMA_BF16 = 1 };
+
+/* `zeroed` argument of the entry points that merge partial results with atomics (weight gradients, split-K partial
+ * tiles, routing gradients): what the caller guarantees to be all zeros on entry -- the callee then skips its own
+ * memset.  A training step keeps ONE zeroed arena and hands out slices of it (~60 memset launches per step gone).
+ * COMA_ZEROED_OUT: the output the call accumulates into (dwk / dr); COMA_ZEROED_WS: the first *_ws_bytes() bytes of
+ * `ws`, which must then be private to this call (the callee leaves them dirty).  0 = the callee zeroes what it needs. */
+enum { COMA_ZEROED_OUT = 1, COMA_ZEROED_WS = 2 };
 
 /* activation after a normalisation (MONAI ADN "A" slot) */
 enum {
@@ -99,10 +109,11 @@ int coma_weight_prep(const float* master, const float* r, int32_t E, int32_t Bw,
 int coma_weight_prep_pair(const float* master, const float* r, int32_t E, int32_t Bw, int32_t A,
                           int32_t B, void* out_ab, int32_t dtype_ab, void* out_ba, int32_t dtype_ba,
                           void* stream);
-/* dwk: fp32 [Bw][taps][N][C]  ->  dmaster (=, fp32, master layout), dr [Bw][E] (=, fp32) */
+/* dwk: fp32 [Bw][taps][N][C]  ->  dmaster (=, fp32, master layout), dr [Bw][E] (=, fp32; accumulated with
+ * atomics: zeroed here unless `zeroed` has COMA_ZEROED_OUT, i.e. the caller hands over a dr that is already zero) */
 int coma_weight_prep_bwd(const float* dwk, const float* master, const float* r, int32_t E,
                          int32_t Bw, int32_t N, int32_t C, int32_t taps, int64_t se,
-                         int64_t sn, int64_t sc, float* dmaster, float* dr, void* stream);
+                         int64_t sn, int64_t sc, float* dmaster, float* dr, int32_t zeroed, void* stream);
 
 /* ---- CondConv routing (call sites attn_unet_data_parallel.py:285-306):
  *      r[b][e] = sigmoid(cov[b] . Wr[e] + br[e]);  bias_mix[b][n] = sum_e r[b][e] * bias_e[e][n]
@@ -128,38 +139,38 @@ int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
  * ws_bytes >= coma_conv_fwd_ws_bytes(...) enables it; a smaller or NULL ws runs the unsplit kernel.          */
 size_t coma_conv_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int coma_conv_fwd_ws(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
-                     const float* bias, const coma_tensor* y, void* ws, size_t ws_bytes, void* stream);
+                     const float* bias, const coma_tensor* y, void* ws, size_t ws_bytes, int32_t zeroed, void* stream);
 /* conv forward + statistics of the BatchNorm(train)/InstanceNorm that follows it (MONAI Convolution =
- * conv -> ADN): the partial sums come out of the conv epilogue where the kernel supports it, so the conv
- * output is not re-read.  Arguments as coma_conv_fwd + coma_norm_stats (ws >= coma_norm_ws_bytes(y)).   */
+ * conv -> ADN): the conv epilogue ADDS its {sum, sumsq} to `sums` where the kernel supports it, so the conv
+ * output is not re-read; otherwise coma_norm_stats runs behind the conv.  `sums`: see coma_norm_stats.       */
 int coma_conv_fwd_norm_stats(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
-                             const float* bias, const coma_tensor* y, int32_t mode, float eps, float* mean,
-                             float* rstd, float* running_mean, float* running_var, float momentum,
-                             void* ws, size_t ws_bytes, void* stream);
+                             const float* bias, const coma_tensor* y, int32_t mode, double* sums,
+                             void* ws, size_t ws_bytes, int32_t zeroed, void* stream);
 /* dwk[b][tap][n][c] (=) sum_m dy[m][n] * x[pos(m,tap)][c]; fp32; batch-summed when
  * !per_sample_w.  dbias[b][n] (=) sum_m dy[m][n] (may be NULL).                     */
 int coma_conv_wgrad_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
 size_t coma_conv_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
 int coma_conv_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy,
-                    float* dwk, float* dbias, void* ws, size_t ws_bytes, void* stream);
+                    float* dwk, float* dbias, void* ws, size_t ws_bytes, int32_t zeroed, void* stream);
 
 /* ---- BatchNorm3d (train) / InstanceNorm3d + activation  (MONAI ADN "N","A") ---- */
-size_t coma_norm_ws_bytes(const coma_tensor* x);
-/* mean/rstd: fp32 [G][C], G = 1 (batch) or B (instance).  running_* may be NULL;
- * updated as r = (1-momentum)*r + momentum*stat with the unbiased variance.      */
-int coma_norm_stats(const coma_tensor* x, int32_t mode, float eps, float* mean, float* rstd,
-                    float* running_mean, float* running_var, float momentum,
-                    void* ws, size_t ws_bytes, void* stream);
-/* y = act((x - mean)*rstd*gamma + beta); gamma/beta may be NULL; slope: device fp32[1] */
-int coma_norm_act_fwd(const coma_tensor* x, int32_t mode, const float* mean, const float* rstd,
+size_t coma_norm_ws_bytes(const coma_tensor* x);   /* scratch of coma_spatial_mean / the conv bias gradient */
+/* Training statistics are fp64 records sums[G][C][2] = {sum x, sum x^2}, G = 1 (batch) or B (instance), that the
+ * CALLER hands over ZEROED and the producers add to with fp64 atomics; every consumer below derives
+ * mean = sum / R and rstd = 1 / sqrt(sumsq / R - mean^2 + eps) from the record itself (R = voxels per group):
+ * there is no finalise launch and no (mean, rstd) tensor on the training path.                                */
+int coma_norm_stats(const coma_tensor* x, int32_t mode, double* sums, void* stream);
+/* y = act((x - mean)*rstd*gamma + beta); gamma/beta may be NULL; slope: device fp32[1].  Statistics: `sums`
+ * (training) or, when sums == NULL, fp32 mean/rstd [G][C] (eval-mode BatchNorm: running statistics).
+ * running_mean/var (BatchNorm training, may be NULL): r = (1-momentum)*r + momentum*stat, unbiased variance.  */
+int coma_norm_act_fwd(const coma_tensor* x, int32_t mode, const double* sums, float eps, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, int32_t act, const float* slope,
+                      float* running_mean, float* running_var, float momentum, const coma_tensor* y, void* stream);
+/* dx (=); dgamma/dbeta [C] (=); dslope [1] (=); any of the three may be NULL.  bsums: fp64 [G][C][3], ZEROED by
+ * the caller (the backward's own partial sums {sum dz, sum dz*xhat, sum dy*dact/dslope}).                     */
+int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, int32_t mode, const double* sums, float eps,
                       const float* gamma, const float* beta, int32_t act, const float* slope,
-                      const coma_tensor* y, void* stream);
-/* dx (=); dgamma/dbeta [C] (=); dslope [1] (=); any of the three may be NULL */
-int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, int32_t mode,
-                      const float* mean, const float* rstd, const float* gamma,
-                      const float* beta, int32_t act, const float* slope,
-                      const coma_tensor* dx, float* dgamma, float* dbeta, float* dslope,
-                      void* ws, size_t ws_bytes, void* stream);
+                      const coma_tensor* dx, float* dgamma, float* dbeta, float* dslope, double* bsums, void* stream);
 
 /* ---- attention gate pieces (MONAI AttentionBlock, attn_unet_data_parallel.py:139-150) ---- */
 /* out = relu(a + b);  da (=) db (=) dout * [out > 0] */
@@ -173,6 +184,11 @@ int coma_gate_mul_bwd(const coma_tensor* x, const coma_tensor* psi, const coma_t
 /* ---- generic strided element-wise helpers ---- */
 /* dst = a (+ b).  b may be NULL.  a/b with B == 1 broadcast over dst's batch. */
 int coma_add(const coma_tensor* a, const coma_tensor* b, const coma_tensor* dst, void* stream);
+/* dst = dtype_of_dst(src): same grid and channels, any pitches, fp32 <-> bf16 (input staging into padded buffers) */
+int coma_cast_copy(const coma_tensor* src, const coma_tensor* dst, void* stream);
+/* base[off, off + len) = 0 for each of the n (off, len) int64 rows (elements) of the device table `ranges`; max_len = the
+ * longest row (sizes the grid).  One launch for the sparse zero_grad of a flat gradient buffer.                         */
+int coma_zero_ranges(float* base, const int64_t* ranges, int32_t n, int64_t max_len, void* stream);
 /* dst[0] (=) sum_b src[b]  (gradient of a batch-broadcast parameter) */
 int coma_batch_sum(const coma_tensor* src, const coma_tensor* dst, void* stream);
 /* per-sample, per-channel mean over voxels -> fp32 [B][C] (AdaptiveAvgPool3d(1)) */

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in coma_unet.h but not exported"
     lib.coma_abi_version.restype = ctypes.c_int
-    assert lib.coma_abi_version() == 2
+    assert lib.coma_abi_version() == 3
     from coma_unet_amd import _lib
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding table out of sync with the header"
 
