@@ -50,6 +50,7 @@ SIGNATURES = {
     "coma_conv_fwd_norm_stats": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _i32, _vp, _vp, _sz, _i32, _vp]),
     "coma_conv_wgrad_algo": (_i32, [_DP, _TP, _TP]),
     "coma_conv_wgrad_ws_bytes": (_sz, [_DP, _TP, _TP]),
+    "coma_conv_wgrad_zs_bytes": (_sz, [_DP, _TP, _TP]),
     "coma_conv_wgrad": (_i32, [_DP, _TP, _TP, _vp, _vp, _vp, _sz, _i32, _vp]),
     "coma_norm_ws_bytes": (_sz, [_TP]),
     "coma_norm_stats": (_i32, [_TP, _i32, _vp, _vp]),

@@ -103,7 +103,7 @@ extern "C" int coma_conv_fwd_norm_stats(const coma_conv_desc* d, const coma_tens
   const int algo_ = coma_conv_pick_algo(d, x, y);
   if ((algo_ == 2 && wk_dtype == COMA_BF16) || (algo_ == 3 && wk_dtype == COMA_F32)) {
     int fused = 0;
-    const int inst = mode == COMA_NORM_INSTANCE;
+    const int inst = mode == COMA_NORM_INSTANCE ? y->B : 0;      // (the kernels' group count; 0 = one BatchNorm group)
     if (int rc = conv_mfma_fwd(d, x, wk, bias, y, s, (double2*)sums, inst, &fused, ws, ws_bytes, (zeroed & COMA_ZEROED_WS) ? 1 : 0)) return rc;
     if (fused) return 0;
   } else {
@@ -116,6 +116,13 @@ extern "C" size_t coma_conv_wgrad_ws_bytes(const coma_conv_desc* d, const coma_t
   size_t a = coma_norm_ws_bytes(dy);
   size_t b = conv_mfma_wgrad_supported(d, x, dy) ? conv_mfma_wgrad_ws_bytes(d, x, dy) : 0;
   return a > b ? a : b;
+}
+
+// the part of coma_conv_wgrad_ws_bytes() the weight-gradient kernels merge into with atomics (their replica scratch): what
+// a caller with a pre-zeroed arena hands over as `ws` together with COMA_ZEROED_WS (0: nothing of ws needs to be zero)
+extern "C" size_t coma_conv_wgrad_zs_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
+  if (conv_point1_ok(d, x, dy) || coma_conv_wgrad_algo(d, x, dy) < 2) return 0;
+  return conv_mfma_wgrad_ws_bytes(d, x, dy);
 }
 
 extern "C" int coma_conv_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy, float* dwk,

@@ -48,10 +48,15 @@ struct GatherP {
 };
 
 // fused norm statistics: a block ADDS its {sum, sumsq} of one (group, channel) to the caller's zeroed fp64 record
-// (global_atomic_add_f64; every consumer derives mean / rstd from the record: norm.hip, NormStat)
-__device__ __forceinline__ void stat_add(double2* rec, double a, double c) {
-  unsafeAtomicAdd(&rec->x, a);
-  unsafeAtomicAdd(&rec->y, c);
+// rec[COMA_STAT_REPLICAS][G][N][2] (replica stride rounded up to a 64-byte line) with global_atomic_add_f64; every consumer
+// sums the replicas and derives mean / rstd itself (norm.hip, NormStat).  Replicas: float atomics execute at the memory
+// side at ~25 ns per request to one 64-byte line, so a few hundred blocks adding to ONE record would queue for
+// microseconds at the end of the kernel; spread over 8 replicas by block index the queue per line is 8x shorter.
+__device__ __forceinline__ void stat_add(double2* rec, int G, int N, int g, int n, double a, double c) {
+  const long rs = ((long)G * N * 2 + 7) & ~7L;
+  double* q = reinterpret_cast<double*>(rec) + (long)(blockIdx.x & (COMA_STAT_REPLICAS - 1)) * rs + ((long)g * N + n) * 2;
+  unsafeAtomicAdd(q, a);
+  unsafeAtomicAdd(q + 1, c);
 }
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 2) | (chunk ^ ((row >> 2) & 3)); }  // 16-B slot index
@@ -505,7 +510,7 @@ struct Halo2P {
   int st8;             // output rows allow aligned 8-byte (4-channel) stores
   int st16;            // ... and aligned 16-byte (8-channel) stores
   double2* stats;      // optional: per-block {sum, sumsq} of the stored outputs, [chunk][G][N]
-  int stats_inst;      // 1: groups = samples (InstanceNorm), 0: one group (BatchNorm)
+  int stats_inst;      // B: groups = the B samples (InstanceNorm), 0: one group (BatchNorm)
 };
 
 // CK = channels per LDS row (bf16: 32, or 16 for the thin full-resolution layers: one MFMA K step per tap; fp32: 16);
@@ -963,7 +968,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
       double a = 0.0, c = 0.0;
       for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
       const int g = p.stats_inst ? b : 0;
-      stat_add(p.stats + ((long)g * p.N + n0 + tid), a, c);
+      stat_add(p.stats, p.stats_inst ? p.stats_inst : 1, p.N, g, n0 + tid, a, c);
     }
   }
 }
@@ -1246,7 +1251,7 @@ __global__ __launch_bounds__(256, 2) void conv_thin16_k(Thin16P p) {
       double a = 0.0, c = 0.0;
       for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
       const int g = p.stats_inst ? b : 0;
-      stat_add(p.stats + ((long)g * p.N + tid), a, c);
+      stat_add(p.stats, p.stats_inst ? p.stats_inst : 1, p.N, g, tid, a, c);
     }
   }
 }
@@ -1457,7 +1462,7 @@ __global__ __launch_bounds__(256, 2) void conv_thin16f_k(Thin16FP p) {
       double a = 0.0, c = 0.0;
       for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
       const int g = p.stats_inst ? b : 0;
-      stat_add(p.stats + ((long)g * p.N + tid), a, c);
+      stat_add(p.stats, p.stats_inst ? p.stats_inst : 1, p.N, g, tid, a, c);
     }
   }
 }
@@ -1626,7 +1631,7 @@ __global__ __launch_bounds__(256) void conv_mfma_pw_k(PwP p) {
       double a = 0.0, c = 0.0;
       for (int w = 0; w < 4; ++w) { a += (double)red[(w * 64 + tid) * 2]; c += (double)red[(w * 64 + tid) * 2 + 1]; }
       const int g = p.stats_inst ? b : 0;
-      stat_add(p.stats + ((long)g * p.N + tid), a, c);
+      stat_add(p.stats, p.stats_inst ? p.stats_inst : 1, p.N, g, tid, a, c);
     }
   }
 }
@@ -1678,7 +1683,7 @@ bool conv_f32mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const
 }
 
 // split-K factor for a gather launch of `blocks` tiles and `nsteps` K steps (1 = no split)
-static int gather_ksplit(long blocks, int nsteps, bool f32 = false) {
+static int gather_ksplit(long blocks, int nsteps, bool f32) {
   // fp32 MFMA: a K step is 16x the MFMA time of a bf16 one, so the global-load latency per step is covered with one
   // block per CU; split only to fill the chip
   if (f32) {
@@ -1870,10 +1875,21 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
 }
 
 // bytes of workspace with which the deep layers' K loop may be split over more blocks (0: never split)
+static int gather_ksplit(long blocks, int nsteps, bool f32);
 size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (x->dtype == COMA_F32) { if (thin16f_ok(d, x, y) || f32_halo_ok(d, x, y)) return 0; }
   else if (halo_ok(d, x, y) || pw_ok(d, x, y)) return 0;
-  return sizeof(float) * (size_t)y->B * t_vox(y) * y->C <= ((size_t)64 << 20) ? sizeof(float) * (size_t)y->B * t_vox(y) * y->C : 0;
+  const size_t bytes = sizeof(float) * (size_t)y->B * t_vox(y) * y->C;
+  if (bytes > ((size_t)64 << 20)) return 0;
+  // only when launch_gather will really split the K loop (the same arithmetic as there): callers that hand out private
+  // pre-zeroed scratch should not be asked for megabytes a launch never touches
+  const bool f32 = x->dtype == COMA_F32;
+  const int BN = y->C % 128 == 0 ? 128 : y->C % 64 == 0 ? 64 : 32, BM = BN == 128 ? 128 : 256, LCK = f32 ? 4 : 5;
+  const int mode = d->form == 1 && d->stride == 2;
+  const long Mtot = mode ? (long)((y->D + 1) / 2) * ((y->H + 1) / 2) * ((y->W + 1) / 2) : (long)t_vox(y);
+  const long gx = (Mtot + BM - 1) / BM, gy = (long)(y->C / BN) * (mode ? 8 : 1);
+  const int taps = d->ksize * d->ksize * d->ksize;
+  return gather_ksplit(gx * gy * y->B, (mode ? 1 : taps) * (x->C >> LCK), f32) > 1 ? bytes : 0;
 }
 
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,

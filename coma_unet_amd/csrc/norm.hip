@@ -62,24 +62,44 @@ struct RowWalk {
 // (fp64 sums of per-block fp64 partials: the order of the atomic adds moves the result by ~1e-16 relative, far below the
 // fp32 mean / rstd every consumer rounds to.)  Eval-mode BatchNorm passes fp32 mean / rstd arrays instead.
 struct NormStat {
-  const double* sums; double R; float eps;
+  const double* sums; int64_t rs;      // record [COMA_STAT_REPLICAS][G][C][2], replica stride rs (doubles)
+  double R; float eps;
   const float* mean; const float* rstd;
 };
+__device__ __forceinline__ double rec_get(const double* rec, int64_t rs, int64_t i) {      // value i summed over the replicas
+  double v = 0.0;
+#pragma unroll
+  for (int r = 0; r < COMA_STAT_REPLICAS; ++r) v += rec[r * rs + i];
+  return v;
+}
 __device__ __forceinline__ void norm_mr(const NormStat& q, int i, float& mu, float& rs) {
   if (q.sums) {
-    const double m = q.sums[2 * i] / q.R;
-    double var = q.sums[2 * i + 1] / q.R - m * m;
+    const double m = rec_get(q.sums, q.rs, 2 * (int64_t)i) / q.R;
+    double var = rec_get(q.sums, q.rs, 2 * (int64_t)i + 1) / q.R - m * m;
     if (var < 0.0) var = 0.0;
     mu = (float)m;
     rs = (float)(1.0 / sqrt(var + (double)q.eps));
   } else { mu = q.mean[i]; rs = q.rstd[i]; }
 }
+// Per-block coefficient tables in LDS: a consumer block derives the (mean, rstd) of its group's channels ONCE (16 L2
+// reads per channel: 8 replicas x {sum, sumsq}) instead of once per thread.
+#define NORM_TAB 1024
+__device__ __forceinline__ void norm_table(const NormStat& q, int g, int C, float* t_mu, float* t_rs) {   // whole block
+  for (int c = threadIdx.x; c < C; c += blockDim.x) norm_mr(q, g * C + c, t_mu[c], t_rs[c]);
+  __syncthreads();
+}
 
 __device__ __forceinline__ void add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }      // global_atomic_add_f64
+// the block's reduced values rec_blk[0 .. n) -> replica (blockIdx.x & 7) of the record, lane i adding value i: one
+// wave instruction covers 64 consecutive doubles = 8 lines, each touched once per block
+__device__ __forceinline__ void rec_add(double* rec, int64_t rs, int64_t base, const double* rec_blk, int n) {
+  double* dst = rec + (int64_t)(blockIdx.x & (COMA_STAT_REPLICAS - 1)) * rs + base;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) add_f64(dst + t, rec_blk[t]);
+}
 
 // sums[(g*C + c)*2 .. +2] += {sum, sumsq} over the block's chunk of rows
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double* sums, double2* partial) {
+__global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double* sums, int64_t rs, double2* partial) {
   __shared__ double sh[256][2 * VEC];
   const int tid = threadIdx.x, tx = tid % p.cvp, ty = tid / p.cvp;
   const int g = blockIdx.y;
@@ -137,13 +157,12 @@ __global__ __launch_bounds__(256) void stats_partial_k(RowsP p, double* sums, do
     }
     __syncthreads();
   }
-  if (ty == 0 && tx < p.cv) {
+  // row 0 of the tree holds the block's sums as sh[tx][2 VEC] = a contiguous [C][2] image
+  if (sums) rec_add(sums, rs, (int64_t)g * p.C * 2, &sh[0][0], p.C * 2);
+  else if (ty == 0 && tx < p.cv) {                     // (colsum / spatial mean: per-chunk partial rows)
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const int64_t i = (int64_t)g * p.C + tx * VEC + j;
-      if (sums) { add_f64(sums + 2 * i, sh[tid][2 * j]); add_f64(sums + 2 * i + 1, sh[tid][2 * j + 1]); }
-      else partial[((int64_t)blockIdx.x * p.G + g) * p.C + tx * VEC + j] = make_double2(sh[tid][2 * j], sh[tid][2 * j + 1]);   // (colsum / spatial mean)
-    }
+    for (int j = 0; j < VEC; ++j)
+      partial[((int64_t)blockIdx.x * p.G + g) * p.C + tx * VEC + j] = make_double2(sh[tid][2 * j], sh[tid][2 * j + 1]);
   }
 }
 
@@ -161,7 +180,7 @@ struct ApplyP {
   const float *gamma, *beta, *slope;
   int act;
   float *rmean, *rvar; float momentum;      // forward, BatchNorm(train): running statistics updated by block (0, 0)
-  const double* bsums;                      // backward: [G][C][3] {sum dz, sum dz*xhat, sum dy*dact/dslope}
+  const double* bsums; int64_t brs;         // backward: [replica][G][C][3] {sum dz, sum dz*xhat, sum dy*dact/dslope}, replica stride
   float *dgamma, *dbeta, *dslope;           // backward: written by block (0, 0)
 };
 
@@ -175,29 +194,32 @@ __global__ __launch_bounds__(256) void norm_act_fwd_k(ApplyP p) {
   const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.sbx;
   T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * p.sby;
   const int g = p.inst ? b : 0;
+  __shared__ float t_sc[NORM_TAB], t_sh[NORM_TAB];
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float mu, rs; norm_mr(p.st, g * p.C + c, mu, rs);
+    const float ga = p.gamma ? p.gamma[c] : 1.f;
+    t_sc[c] = rs * ga;
+    t_sh[c] = (p.gamma ? p.beta[c] : 0.f) - mu * rs * ga;
+  }
   if (p.rmean && blockIdx.x == 0 && b == 0) {
     // BatchNorm3d(train): running_mean / running_var <- (1 - m) * old + m * {batch mean, unbiased batch variance}
     for (int c = threadIdx.x; c < p.C; c += 256) {
-      const double m = p.st.sums[2 * c] / p.st.R;
-      double var = p.st.sums[2 * c + 1] / p.st.R - m * m;
+      const double m = rec_get(p.st.sums, p.st.rs, 2 * c) / p.st.R;
+      double var = rec_get(p.st.sums, p.st.rs, 2 * c + 1) / p.st.R - m * m;
       if (var < 0.0) var = 0.0;
       const double unb = p.st.R > 1.0 ? var * p.st.R / (p.st.R - 1.0) : var;
       p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * (float)m;
       p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)unb;
     }
   }
+  __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * 256, e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (stride % p.cv == 0) {
     // the thread keeps its channel group for the whole sweep: scale / shift live in registers, no division in the loop
     const int c0 = (int)(e0 % p.cv) * VEC;
     float sc[VEC], sh[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float mu, rs; norm_mr(p.st, g * p.C + c0 + j, mu, rs);
-      const float ga = p.gamma ? p.gamma[c0 + j] : 1.f;
-      sc[j] = rs * ga;
-      sh[j] = (p.gamma ? p.beta[c0 + j] : 0.f) - mu * rs * ga;
-    }
+    for (int j = 0; j < VEC; ++j) { sc[j] = t_sc[c0 + j]; sh[j] = t_sh[c0 + j]; }
     const int64_t dv = stride / p.cv;
     int64_t v = e0 / p.cv;
     for (; v + (NORM_UNR - 1) * dv < p.V; v += NORM_UNR * dv) {
@@ -226,13 +248,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_k(ApplyP p) {
     float xv[VEC], yv[VEC];
     vec_io<T, VEC>::load(xb + v * p.ldx + c0, xv);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const int c = c0 + j;
-      float mu, rs; norm_mr(p.st, g * p.C + c, mu, rs);
-      const float ga = p.gamma ? p.gamma[c] : 1.f;
-      const float sc = rs * ga, sh = (p.gamma ? p.beta[c] : 0.f) - mu * rs * ga;     // (the same arithmetic as the fast path)
-      yv[j] = act_fwd(p.act, fmaf(xv[j], sc, sh), a);
-    }
+    for (int j = 0; j < VEC; ++j) yv[j] = act_fwd(p.act, fmaf(xv[j], t_sc[c0 + j], t_sh[c0 + j]), a);
     vec_io<T, VEC>::store(yb + v * p.ldy + c0, yv);
   }
 }
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_k(ApplyP p) {
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* dyp, int64_t lddy, int64_t sbdy,
                                                           NormStat st, const float* gamma, const float* beta, int act,
-                                                          const float* slope, double* bsums) {
+                                                          const float* slope, double* bsums, int64_t brs) {
   __shared__ double sh[256][3 * VEC];
   const int tid = threadIdx.x, tx = tid % p.cvp, ty = tid / p.cvp;
   const int g = blockIdx.y;
@@ -251,6 +267,8 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
   double s1[VEC], s2[VEC], s3[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { s1[j] = s2[j] = s3[j] = 0.0; }
+  __shared__ float t_mu[NORM_TAB], t_rs[NORM_TAB];
+  norm_table(st, g, p.C, t_mu, t_rs);
   if (tx < p.cv) {
     const T* xb = reinterpret_cast<const T*>(p.x);
     const T* dyb = reinterpret_cast<const T*>(dyp);
@@ -258,7 +276,7 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int c = tx * VEC + j;
-      norm_mr(st, g * p.C + c, mu[j], rs[j]);
+      mu[j] = t_mu[c]; rs[j] = t_rs[c];
       ga[j] = gamma ? gamma[c] : 1.f; be[j] = gamma ? beta[c] : 0.f;
     }
     // bf16: fp32 partial sums over bursts of 8 rows folded into fp64; fp32: every term straight to fp64 -- see
@@ -309,13 +327,7 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
     }
     __syncthreads();
   }
-  if (ty == 0 && tx < p.cv) {
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      double* o = bsums + ((int64_t)g * p.C + tx * VEC + j) * 3;
-      add_f64(o, sh[tid][3 * j]); add_f64(o + 1, sh[tid][3 * j + 1]); add_f64(o + 2, sh[tid][3 * j + 2]);
-    }
-  }
+  rec_add(bsums, brs, (int64_t)g * p.C * 3, &sh[0][0], p.C * 3);      // row 0 of the tree = a contiguous [C][3] image
 }
 
 // backward pass 2: dx = rstd * gamma * (dz - mean(dz) - xhat * mean(dz * xhat)); block (0, 0) also writes the parameter
@@ -330,14 +342,20 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p) {
   T* ob = reinterpret_cast<T*>(p.y) + (int64_t)b * p.sby;
   const int g = p.inst ? b : 0;
   const int G = p.inst ? p.B : 1;
+  __shared__ float t_mu[NORM_TAB], t_rs[NORM_TAB], t_s1[NORM_TAB], t_s2[NORM_TAB];
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    norm_mr(p.st, g * p.C + c, t_mu[c], t_rs[c]);
+    t_s1[c] = (float)(rec_get(p.bsums, p.brs, ((int64_t)g * p.C + c) * 3) / p.st.R);
+    t_s2[c] = (float)(rec_get(p.bsums, p.brs, ((int64_t)g * p.C + c) * 3 + 1) / p.st.R);
+  }
   if (blockIdx.x == 0 && b == 0 && (p.dgamma || p.dbeta || p.dslope)) {
     __shared__ double ssl[256];
     double sl = 0.0;
     for (int c = threadIdx.x; c < p.C; c += 256) {
       double dg = 0.0, db = 0.0;
       for (int gg = 0; gg < G; ++gg) {
-        const double* t = p.bsums + ((int64_t)gg * p.C + c) * 3;
-        db += t[0]; dg += t[1]; sl += t[2];
+        const int64_t i = ((int64_t)gg * p.C + c) * 3;
+        db += rec_get(p.bsums, p.brs, i); dg += rec_get(p.bsums, p.brs, i + 1); sl += rec_get(p.bsums, p.brs, i + 2);
       }
       if (p.dgamma) p.dgamma[c] = (float)dg;
       if (p.dbeta) p.dbeta[c] = (float)db;
@@ -349,6 +367,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p) {
       if (threadIdx.x == 0) *p.dslope = (float)ssl[0];
     }
   }
+  __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * 256, e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (stride % p.cv == 0) {      // fixed channel group per thread: the per-channel constants live in registers
     const int c0 = (int)(e0 % p.cv) * VEC;
@@ -356,9 +375,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int c = c0 + j;
-      norm_mr(p.st, g * p.C + c, mu[j], rs[j]);
+      mu[j] = t_mu[c]; rs[j] = t_rs[c]; s1[j] = t_s1[c]; s2[j] = t_s2[c];
       ga[j] = p.gamma ? p.gamma[c] : 1.f; be[j] = p.gamma ? p.beta[c] : 0.f;
-      s1[j] = (float)(p.bsums[((int64_t)g * p.C + c) * 3] / p.st.R); s2[j] = (float)(p.bsums[((int64_t)g * p.C + c) * 3 + 1] / p.st.R);
     }
     auto one = [&](const float* xv, const float* dv, float* ov) {
 #pragma unroll
@@ -404,14 +422,12 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_k(ApplyP p) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int c = c0 + j;
-      float mu, rs; norm_mr(p.st, g * p.C + c, mu, rs);
-      const float xh = (xv[j] - mu) * rs;
+      const float rs = t_rs[c], xh = (xv[j] - t_mu[c]) * rs;
       const float ga = p.gamma ? p.gamma[c] : 1.f;
       const float z = p.gamma ? xh * ga + p.beta[c] : xh;
       float ds; const float da = act_bwd(p.act, z, a, &ds);
       const float dz = dv[j] * da;
-      const float s1 = (float)(p.bsums[((int64_t)g * p.C + c) * 3] / p.st.R), s2 = (float)(p.bsums[((int64_t)g * p.C + c) * 3 + 1] / p.st.R);
-      ov[j] = rs * ga * (dz - s1 - xh * s2);
+      ov[j] = rs * ga * (dz - t_s1[c] - xh * t_s2[c]);
     }
     vec_io<T, VEC>::store(ob + v * p.ldy + c0, ov);
   }
@@ -438,11 +454,11 @@ extern "C" size_t coma_norm_ws_bytes(const coma_tensor* x) {
 }
 
 template <typename T>
-static void launch_partial(const RowsP& p, int vec, double* sums, double2* partial, hipStream_t s) {
+static void launch_partial(const RowsP& p, int vec, double* sums, int64_t rs, double2* partial, hipStream_t s) {
   dim3 grid(p.nchunks, p.G);
-  if (vec == 8) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((stats_partial_k<T, 8>), grid, dim3(256), 0, s, p, sums, partial); }
-  else if (vec == 4) hipLaunchKernelGGL((stats_partial_k<T, 4>), grid, dim3(256), 0, s, p, sums, partial);
-  else hipLaunchKernelGGL((stats_partial_k<T, 1>), grid, dim3(256), 0, s, p, sums, partial);
+  if (vec == 8) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((stats_partial_k<T, 8>), grid, dim3(256), 0, s, p, sums, rs, partial); }
+  else if (vec == 4) hipLaunchKernelGGL((stats_partial_k<T, 4>), grid, dim3(256), 0, s, p, sums, rs, partial);
+  else hipLaunchKernelGGL((stats_partial_k<T, 1>), grid, dim3(256), 0, s, p, sums, rs, partial);
 }
 
 // sums != NULL: atomic adds into the caller's zeroed [G][C][2] record; else per-chunk partial rows in `ws`
@@ -452,8 +468,10 @@ static int run_partial(const coma_tensor* x, int mode, RowsP& p, double* sums, v
   const int vec = pick_vec8(x);
   p = make_rows(x, mode, vec);
   COMA_CHECK(p.cv <= 256, "norm: C=%d too large", x->C);
-  if (x->dtype == COMA_F32) launch_partial<float>(p, vec, sums, (double2*)ws, s);
-  else launch_partial<bf16_t>(p, vec, sums, (double2*)ws, s);
+  COMA_CHECK(x->C <= NORM_TAB, "norm: C=%d above the coefficient table size", x->C);
+  const int64_t rs = COMA_NORM_RECORD_DOUBLES(p.G, p.C, 2);
+  if (x->dtype == COMA_F32) launch_partial<float>(p, vec, sums, rs, (double2*)ws, s);
+  else launch_partial<bf16_t>(p, vec, sums, rs, (double2*)ws, s);
   COMA_LAUNCH_CHECK();
   return 0;
 }
@@ -492,13 +510,14 @@ static ApplyP make_apply(const coma_tensor* x, const coma_tensor* y, int mode, i
   p.y = y->data; p.ldy = y->ld; p.sby = y->sb;
   p.dy = nullptr; p.lddy = 0; p.sbdy = 0;
   p.V = t_vox(x); p.B = x->B; p.C = x->C; p.cv = x->C / vec; p.inst = mode == COMA_NORM_INSTANCE;
-  p.rmean = p.rvar = nullptr; p.momentum = 0.f; p.bsums = nullptr; p.dgamma = p.dbeta = p.dslope = nullptr;
+  p.rmean = p.rvar = nullptr; p.momentum = 0.f; p.bsums = nullptr; p.brs = 0; p.dgamma = p.dbeta = p.dslope = nullptr;
   return p;
 }
 
 static NormStat make_stat(const coma_tensor* x, int mode, const double* sums, float eps, const float* mean, const float* rstd) {
   NormStat st;
   st.sums = sums; st.eps = eps; st.mean = mean; st.rstd = rstd;
+  st.rs = COMA_NORM_RECORD_DOUBLES(mode == COMA_NORM_INSTANCE ? x->B : 1, x->C, 2);
   st.R = (double)(mode == COMA_NORM_INSTANCE ? t_vox(x) : t_vox(x) * x->B);
   return st;
 }
@@ -522,6 +541,7 @@ extern "C" int coma_norm_act_fwd(const coma_tensor* x, int32_t mode, const doubl
   hipStream_t s = (hipStream_t)stream;
   COMA_CHECK(x && y && x->data && y->data && (sums || (mean && rstd)), "norm_act_fwd: null argument");
   COMA_CHECK(t_same_grid(x, y) && x->C == y->C && x->dtype == y->dtype, "norm_act_fwd: shape/dtype mismatch");
+  COMA_CHECK(x->C <= NORM_TAB, "norm: C=%d above the coefficient table size", x->C);
   COMA_CHECK(!running_mean || (sums && running_var && mode == COMA_NORM_BATCH), "norm_act_fwd: running statistics need a BatchNorm sums record");
   int vec = (pick_vec(x) == 4 && pick_vec(y) == 4) ? 4 : 1;
   if (x->dtype == COMA_BF16 && t_vec(x, 8) == 8 && t_vec(y, 8) == 8) vec = 8;     // 16 bytes per lane
@@ -550,10 +570,12 @@ extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, in
   const int pvec = vec;     // (8-wide measured slower here: 24 fp64 accumulators per lane, 48 KB of LDS)
   RowsP rp = make_rows(x, mode, pvec);
   COMA_CHECK(rp.cv <= 256, "norm: C=%d too large", x->C);
+  COMA_CHECK(x->C <= NORM_TAB, "norm: C=%d above the coefficient table size", x->C);
   const NormStat st = make_stat(x, mode, sums, eps, nullptr, nullptr);
+  const int64_t brs = COMA_NORM_RECORD_DOUBLES(rp.G, rp.C, 3);
   dim3 pg(rp.nchunks, rp.G);
 #define L(T, V) hipLaunchKernelGGL((norm_bwd_partial_k<T, V>), pg, dim3(256), 0, s, rp, dy->data, dy->ld, dy->sb, \
-                                   st, gamma, beta, act, slope, bsums)
+                                   st, gamma, beta, act, slope, bsums, brs)
   if (x->dtype == COMA_F32) { if (pvec == 4) L(float, 4); else L(float, 1); }
   else { if (pvec == 4) L(bf16_t, 4); else L(bf16_t, 1); }
 #undef L
@@ -564,7 +586,7 @@ extern "C" int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, in
   p.dy = dy->data; p.lddy = dy->ld; p.sbdy = dy->sb;
   p.st = st;
   p.gamma = gamma; p.beta = beta; p.slope = slope; p.act = act;
-  p.bsums = bsums; p.dgamma = dgamma; p.dbeta = dbeta; p.dslope = dslope;
+  p.bsums = bsums; p.brs = brs; p.dgamma = dgamma; p.dbeta = dbeta; p.dslope = dslope;
   dim3 grid(apply_blocks(p.V * p.cv, p.cv, NORM_UNR / 2), x->B);
 #define L(T, V) hipLaunchKernelGGL((norm_act_bwd_apply_k<T, V>), grid, dim3(256), 0, s, p)
   if (x->dtype == COMA_F32) { if (avec == 4) L(float, 4); else L(float, 1); }

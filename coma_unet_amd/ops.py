@@ -127,6 +127,7 @@ class ZeroArena:
         self.cur = 0
         self.armed = False
         self.missed = 0          # bytes requests that did not fit (diagnostic)
+        self.peak = 0            # most bytes one step has used (diagnostic)
 
     @classmethod
     def get(cls, device):
@@ -152,6 +153,7 @@ class ZeroArena:
 
     def clean(self):
         if self.cur:
+            self.peak = max(self.peak, self.cur)
             self.buf[:self.cur].zero_()
             self.cur = 0
 
@@ -173,17 +175,26 @@ class ZeroArena:
         return t if dtype == torch.uint8 else t.view(dtype)
 
 
-def _zeros_f64(n, device):
-    """A zeroed fp64 record (statistics of one normalisation): arena slice, else a fresh torch.zeros."""
-    t = ZeroArena.take(8 * n, device, torch.float64)
-    return t if t is not None else torch.zeros(n, dtype=torch.float64, device=device)
+STAT_REPLICAS = 8      # COMA_STAT_REPLICAS of include/coma_unet.h
 
 
-def stats_from_sums(sums, count, eps):
-    """(mean, rstd) fp32 of a statistics record [G, C, 2] = {sum, sumsq} -- what every kernel derives on the fly
-    (csrc/norm.hip, NormStat); host-side twin for tests and diagnostics."""
-    m = sums[..., 0] / count
-    var = (sums[..., 1] / count - m * m).clamp_min(0.0)
+def stat_record(G, C, k, device):
+    """A zeroed fp64 statistics record [STAT_REPLICAS, stride] with stride = G*C*k rounded up to a 64-byte line
+    (COMA_NORM_RECORD_DOUBLES): arena slice, else a fresh torch.zeros."""
+    rs = (G * C * k + 7) & ~7
+    t = ZeroArena.take(8 * STAT_REPLICAS * rs, device, torch.float64)
+    if t is None:
+        t = torch.zeros(STAT_REPLICAS * rs, dtype=torch.float64, device=device)
+    return t.view(STAT_REPLICAS, rs)
+
+
+def stats_from_sums(sums, G, C, count, eps):
+    """(mean, rstd) fp32 [G, C] of a forward statistics record -- what every kernel derives on the fly (csrc/norm.hip,
+    NormStat: replicas summed, mean = sum / count, rstd = 1 / sqrt(sumsq / count - mean^2 + eps)); host-side twin for
+    tests and diagnostics."""
+    t = sums.sum(0)[:G * C * 2].view(G, C, 2)
+    m = t[..., 0] / count
+    var = (t[..., 1] / count - m * m).clamp_min(0.0)
     return m.float(), (1.0 / torch.sqrt(var + eps)).float()
 
 
@@ -484,7 +495,7 @@ def _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm):
         return y, None
     mode = norm[0] if isinstance(norm, (tuple, list)) else norm
     G = B if mode == L.NORM_INSTANCE else 1
-    sums = _zeros_f64(G * n * 2, x.device).view(G, n, 2)
+    sums = stat_record(G, n, 2, x.device)
     KernelTimer.run("conv_fwd", kind, conv_flops(x.shape, y.shape, ksize, stride),
                     lambda: check(lib.coma_conv_fwd_norm_stats(d, ct(x), ptr(wk_f), L.dtype_code(wk_f.dtype), ptr(b), cy,
                                                                mode, ptr(sums), ptr(ws), ws.numel(), zf, L.stream()),
@@ -512,9 +523,12 @@ def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_d
     if need_dw:
         d = _desc(ksize, stride, form, per_sample, algo)
         cx, cdy = ct(x), ct(dy)
-        nws = lib.coma_conv_wgrad_ws_bytes(d, cx, cdy)
-        # a bias reduction writes its partial rows into the scratch first: shared workspace then (nothing pre-zeroed)
-        ws, zf = _scratch(nws, x.device) if bias_mode != 1 else (workspace(nws, x.device), 0)
+        # scratch: the replicas the kernels merge into must be zero -- a private arena slice of just that size when the
+        # step's arena is armed (a bias reduction writes its partial rows into the scratch first: shared workspace then)
+        nzs = lib.coma_conv_wgrad_zs_bytes(d, cx, cdy) if bias_mode != 1 else 0
+        ws, zf = _scratch(nzs, x.device) if nzs > 0 else (None, 0)
+        if not zf:
+            ws = workspace(lib.coma_conv_wgrad_ws_bytes(d, cx, cdy), x.device)
         nel = 1
         for k_ in wshape:
             nel *= k_
@@ -659,7 +673,7 @@ class NormAct(Function):
         if pre is not None:          # statistics already produced by the conv that wrote x
             sums = pre
         elif use_batch_stats:
-            sums = _zeros_f64(G * C * 2, dev).view(G, C, 2)
+            sums = stat_record(G, C, 2, dev)
             check(lib.coma_norm_stats(cx, mode, ptr(sums), s), "coma_norm_stats")
         else:
             mean = rmean.reshape(1, C).float().contiguous()
@@ -687,7 +701,7 @@ class NormAct(Function):
         dgamma = sinks[0] if sinks[0] is not None else (_f32(C, dev) if gamma is not None else None)
         dbeta = sinks[1] if sinks[1] is not None else (_f32(C, dev) if beta is not None else None)
         dslope = sinks[2] if sinks[2] is not None else (_f32(1, dev) if slope is not None else None)
-        bsums = _zeros_f64(G * C * 3, dev)
+        bsums = stat_record(G, C, 3, dev)
         check(lib.coma_norm_act_bwd(ct(x), ct(dy), mode, ptr(sums), eps, ptr(gamma), ptr(beta), act, ptr(slope),
                                     ct(dx), ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(bsums), L.stream()),
               "coma_norm_act_bwd")

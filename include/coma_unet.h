@@ -150,15 +150,22 @@ int coma_conv_fwd_norm_stats(const coma_conv_desc* d, const coma_tensor* x, cons
  * !per_sample_w.  dbias[b][n] (=) sum_m dy[m][n] (may be NULL).                     */
 int coma_conv_wgrad_algo(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
 size_t coma_conv_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
+/* the part of it that must be ZERO for the kernels' atomic merges (0 = none): with COMA_ZEROED_WS and dbias == NULL a
+ * caller may pass a private pre-zeroed buffer of just this size as `ws`                                          */
+size_t coma_conv_wgrad_zs_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
 int coma_conv_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy,
                     float* dwk, float* dbias, void* ws, size_t ws_bytes, int32_t zeroed, void* stream);
 
 /* ---- BatchNorm3d (train) / InstanceNorm3d + activation  (MONAI ADN "N","A") ---- */
 size_t coma_norm_ws_bytes(const coma_tensor* x);   /* scratch of coma_spatial_mean / the conv bias gradient */
-/* Training statistics are fp64 records sums[G][C][2] = {sum x, sum x^2}, G = 1 (batch) or B (instance), that the
- * CALLER hands over ZEROED and the producers add to with fp64 atomics; every consumer below derives
- * mean = sum / R and rstd = 1 / sqrt(sumsq / R - mean^2 + eps) from the record itself (R = voxels per group):
- * there is no finalise launch and no (mean, rstd) tensor on the training path.                                */
+/* Training statistics are fp64 records sums[COMA_STAT_REPLICAS][G][C][2] = {sum x, sum x^2}, G = 1 (batch) or B
+ * (instance), replica stride COMA_NORM_RECORD_DOUBLES(G, C, 2), that the CALLER hands over ZEROED and the producers add
+ * to with fp64 atomics (a block picks a replica by its index: short queues at the memory-side atomic units); every
+ * consumer below sums the replicas and derives mean = sum / R and rstd = 1 / sqrt(sumsq / R - mean^2 + eps) itself
+ * (R = voxels per group): there is no finalise launch and no (mean, rstd) tensor on the training path.             */
+#define COMA_STAT_REPLICAS 8
+/* doubles in ONE replica of a record with k values per (group, channel), rounded up to a 64-byte line */
+#define COMA_NORM_RECORD_DOUBLES(G, C, k) ((((int64_t)(G) * (C) * (k)) + 7) & ~(int64_t)7)
 int coma_norm_stats(const coma_tensor* x, int32_t mode, double* sums, void* stream);
 /* y = act((x - mean)*rstd*gamma + beta); gamma/beta may be NULL; slope: device fp32[1].  Statistics: `sums`
  * (training) or, when sums == NULL, fp32 mean/rstd [G][C] (eval-mode BatchNorm: running statistics).
@@ -166,8 +173,9 @@ int coma_norm_stats(const coma_tensor* x, int32_t mode, double* sums, void* stre
 int coma_norm_act_fwd(const coma_tensor* x, int32_t mode, const double* sums, float eps, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, int32_t act, const float* slope,
                       float* running_mean, float* running_var, float momentum, const coma_tensor* y, void* stream);
-/* dx (=); dgamma/dbeta [C] (=); dslope [1] (=); any of the three may be NULL.  bsums: fp64 [G][C][3], ZEROED by
- * the caller (the backward's own partial sums {sum dz, sum dz*xhat, sum dy*dact/dslope}).                     */
+/* dx (=); dgamma/dbeta [C] (=); dslope [1] (=); any of the three may be NULL.  bsums: fp64
+ * [COMA_STAT_REPLICAS][G][C][3] (replica stride COMA_NORM_RECORD_DOUBLES(G, C, 3)), ZEROED by the caller: the
+ * backward's own partial sums {sum dz, sum dz*xhat, sum dy*dact/dslope}.                                         */
 int coma_norm_act_bwd(const coma_tensor* x, const coma_tensor* dy, int32_t mode, const double* sums, float eps,
                       const float* gamma, const float* beta, int32_t act, const float* slope,
                       const coma_tensor* dx, float* dgamma, float* dbeta, float* dslope, double* bsums, void* stream);

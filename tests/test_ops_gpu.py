@@ -637,7 +637,7 @@ def test_thin16_kernel_fwd_dgrad_and_fused_stats(case, mode):
     y, sums = ops._conv_fwd(xi, wk_f, bias.cuda(), k, 1, 0, per_sample, 2, None, norm)
     assert lib.coma_last_kernel().decode().startswith("conv_thin16_k"), lib.coma_last_kernel()
     if norm is not None:      # the kernels derive (mean, rstd) from the fp64 {sum, sumsq} record: same arithmetic here
-        mean, rstd = ops.stats_from_sums(sums, y.shape[1] * y.shape[2] * y.shape[3] * (1 if mode == "instance" else y.shape[0]), 1e-5)
+        mean, rstd = ops.stats_from_sums(sums, y.shape[0] if mode == "instance" else 1, y.shape[4], y.shape[1] * y.shape[2] * y.shape[3] * (1 if mode == "instance" else y.shape[0]), 1e-5)
     assert torch.isfinite(y.float()).all() and rel(to_ext(y), yr) < 5e-3
     if norm is not None:
         yf = y.double()
@@ -740,7 +740,7 @@ def test_thin16f_kernel_fp32_fwd_dgrad_and_fused_stats(case, mode):
     y, sums = ops._conv_fwd(xi, wk_f, bias.cuda(), k, 1, 0, per_sample, 0, None, norm)
     assert lib.coma_last_kernel().decode().startswith("conv_thin16f_k"), lib.coma_last_kernel()
     if norm is not None:
-        mean, rstd = ops.stats_from_sums(sums, y.shape[1] * y.shape[2] * y.shape[3] * (1 if mode == "instance" else y.shape[0]), 1e-5)
+        mean, rstd = ops.stats_from_sums(sums, y.shape[0] if mode == "instance" else 1, y.shape[4], y.shape[1] * y.shape[2] * y.shape[3] * (1 if mode == "instance" else y.shape[0]), 1e-5)
     assert torch.isfinite(y).all() and rel(to_ext(y), yr) < 3e-6
     if norm is not None:
         yf = y.double()
