@@ -60,6 +60,12 @@ SIGNATURES = {
     "coma_add_relu_bwd": (_i32, [_TP, _TP, _TP, _vp]),
     "coma_gate_mul_fwd": (_i32, [_TP, _TP, _TP, _vp]),
     "coma_gate_mul_bwd": (_i32, [_TP, _TP, _TP, _TP, _i32, _TP, _vp]),
+    "coma_gate_mid_fwd": (_i32, [_TP, _TP, _vp, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32,
+                                 _TP, _TP, _vp, _vp]),
+    "coma_gate_apply_fwd": (_i32, [_TP, _TP, _vp, _f32, _vp, _vp, _vp, _vp, _f32, _TP, _TP, _vp]),
+    "coma_gate_apply_bwd": (_i32, [_TP, _TP, _TP, _TP, _vp, _f32, _vp, _vp, _TP, _i32, _TP, _vp, _vp]),
+    "coma_gate_mid_bwd": (_i32, [_TP, _TP, _TP, _TP, _TP, _vp, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp,
+                                 _TP, _TP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "coma_add": (_i32, [_TP, _TP, _TP, _vp]),
     "coma_cast_copy": (_i32, [_TP, _TP, _vp]),
     "coma_zero_ranges": (_i32, [_vp, _vp, _i32, _i64, _vp]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcoma_unet.so")
-SOURCES = ["api.hip", "conv_direct.hip", "conv_point1.hip", "conv_mfma.hip", "norm.hip", "elementwise.hip", "weights.hip", "metrics.hip", "comm.hip"]
+SOURCES = ["api.hip", "conv_direct.hip", "conv_point1.hip", "conv_mfma.hip", "norm.hip", "gate.hip", "elementwise.hip", "weights.hip", "metrics.hip", "comm.hip"]
 
 
 def _stale(obj, deps):

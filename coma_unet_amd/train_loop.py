@@ -138,6 +138,27 @@ def train_dp(model, criterion, train_loader, validation_loader, epochs, lr, save
     if use_graph:
         assert getattr(model, "static_prompts", False), "train_dp(graph=True) needs a model built with static_prompts=True"
     graphed, eager_done = None, 0
+    # graph mode: the whole loop runs on a side stream, like GraphedTrainStep's own warm-up -- the eager steps that precede
+    # the capture must not have run on the (legacy) default stream (torch.cuda.graph's documented requirement; a capture
+    # right behind default-stream steps crashed in capture_end on ROCm 7.2)
+    import contextlib
+    scope = contextlib.ExitStack()
+    if use_graph and device.type == "cuda":
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        scope.enter_context(torch.cuda.stream(side))
+        scope.callback(lambda: torch.cuda.current_stream(device).wait_stream(side))
+    with scope:
+        return _train_epochs(model, criterion, train_loader, validation_loader, epochs, save_path, cuda_id, pred_sample_file,
+                             kwargs, lookup, get_id, keep, device, optimizer, scheduler, reducer, world, rank, use_graph,
+                             start_epoch, val_iter, overfit_val_iter, checkpoint_iter)
+
+
+def _train_epochs(model, criterion, train_loader, validation_loader, epochs, save_path, cuda_id, pred_sample_file, kwargs, lookup,
+                  get_id, keep, device, optimizer, scheduler, reducer, world, rank, use_graph, start_epoch, val_iter,
+                  overfit_val_iter, checkpoint_iter):
+    import torch.distributed as dist
+    graphed, eager_done = None, 0
     epoch_avg_losses = []
     hist = {k: [] for k in ("mae", "rse", "rrmse", "ssim", "mape", "avg_corr", "roi_maes", "roi_mapes", "roi_wrrmses",
                             "roi_corrs", "roi_rses")}

@@ -189,6 +189,35 @@ int coma_gate_mul_fwd(const coma_tensor* x, const coma_tensor* psi, const coma_t
 int coma_gate_mul_bwd(const coma_tensor* x, const coma_tensor* psi, const coma_tensor* dout,
                       const coma_tensor* dx, int32_t accumulate_dx, const coma_tensor* dpsi, void* stream);
 
+/* ---- the attention gate behind its W_g / W_x convolutions, fused (csrc/gate.hip; attn_unet_data_parallel.py:139-150):
+ *      s = relu(BN_g(g1raw) + BN_x(x1raw));  psi_raw = w_psi . s + b_psi;  psi = sigmoid(BN_psi(psi_raw));  att = x * psi
+ * All three BatchNorms in training mode on statistics records (coma_norm_stats; G = 1): sums_g / sums_x come out of the
+ * W_g / W_x convolutions (coma_conv_fwd_norm_stats), sums_psi is a ZEROED record this call fills.  s and psi_raw are
+ * written for the backward.  running_* may be NULL.                                                                    */
+int coma_gate_mid_fwd(const coma_tensor* g1raw, const coma_tensor* x1raw, const double* sums_g, float eps_g,
+                      const float* gamma_g, const float* beta_g, const double* sums_x, float eps_x,
+                      const float* gamma_x, const float* beta_x, const float* w_psi, const float* b_psi,
+                      float* rmean_g, float* rvar_g, float* rmean_x, float* rvar_x, float momentum,
+                      const coma_tensor* s_out, const coma_tensor* psi_raw, double* sums_psi, void* stream);
+/* psi = sigmoid(BN_psi(psi_raw)) (written: [B][V][1]) and att = x * psi (e.g. a channel slice of the concat buffer) */
+int coma_gate_apply_fwd(const coma_tensor* x, const coma_tensor* psi_raw, const double* sums_psi, float eps,
+                        const float* gamma_psi, const float* beta_psi, float* rmean_psi, float* rvar_psi,
+                        float momentum, const coma_tensor* psi, const coma_tensor* att, void* stream);
+/* dx (= or +=) d(att) * psi;  dz[v] = (sum_c d(att) x) psi (1 - psi);  bsums_psi: ZEROED record, k = 3            */
+int coma_gate_apply_bwd(const coma_tensor* x, const coma_tensor* psi, const coma_tensor* psi_raw,
+                        const coma_tensor* dout, const double* sums_psi, float eps, const float* gamma_psi,
+                        const float* beta_psi, const coma_tensor* dx, int32_t accumulate_dx,
+                        const coma_tensor* dz, double* bsums_psi, void* stream);
+/* dz -> d(psi_raw) -> ds -> relu mask -> both BatchNorm backwards: dg1raw, dx1raw (=) and every parameter gradient (=;
+ * any may be NULL).  rec: ZEROED scratch record [COMA_STAT_REPLICAS][COMA_NORM_RECORD_DOUBLES(1, F, 4)].            */
+int coma_gate_mid_bwd(const coma_tensor* dz, const coma_tensor* psi_raw, const coma_tensor* s_in,
+                      const coma_tensor* g1raw, const coma_tensor* x1raw, const double* sums_psi, float eps_psi,
+                      const float* gamma_psi, const double* bsums_psi, const double* sums_g, float eps_g,
+                      const float* gamma_g, const double* sums_x, float eps_x, const float* gamma_x,
+                      const float* w_psi, double* rec, const coma_tensor* dg1raw, const coma_tensor* dx1raw,
+                      float* dgamma_g, float* dbeta_g, float* dgamma_x, float* dbeta_x, float* dw_psi,
+                      float* dgamma_psi, float* dbeta_psi, void* stream);
+
 /* ---- generic strided element-wise helpers ---- */
 /* dst = a (+ b).  b may be NULL.  a/b with B == 1 broadcast over dst's batch. */
 int coma_add(const coma_tensor* a, const coma_tensor* b, const coma_tensor* dst, void* stream);
