@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COMA_UNET_LIB") or os.path.join(_HERE, "libcoma_unet.so")   # (override: diagnostic builds, profiles/stamps_halo2.py)
 
 F32, BF16 = 0, 1
-ZEROED_OUT, ZEROED_WS = 1, 2
+ZEROED_OUT, ZEROED_WS, ACCUMULATE = 1, 2, 4
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY, ACT_SIGMOID, ACT_PRELU_RELU = range(6)
 NORM_BATCH, NORM_INSTANCE = 0, 1
 
@@ -46,6 +46,7 @@ SIGNATURES = {
     "coma_conv_pick_algo": (_i32, [_DP, _TP, _TP]),
     "coma_conv_fwd": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _vp]),
     "coma_conv_fwd_ws_bytes": (_sz, [_DP, _TP, _TP]),
+    "coma_conv_accumulate_ok": (_i32, [_DP, _TP, _TP]),
     "coma_conv_fwd_ws": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _vp, _sz, _i32, _vp]),
     "coma_conv_fwd_norm_stats": (_i32, [_DP, _TP, _vp, _i32, _vp, _TP, _i32, _vp, _vp, _sz, _i32, _vp]),
     "coma_conv_wgrad_algo": (_i32, [_DP, _TP, _TP]),

@@ -28,7 +28,7 @@ from . import _lib as L
 from . import ops
 from ._lib import lib, ct, check
 from .layers import (Config, Convolution, MonaiConvBlock, CondConvolution, CondConvBlock, norm_act, conv_plain,
-                     conv_then_bn, reset_cov_cache, cov_rows)
+                     conv_then_bn, reset_cov_cache, cov_rows, _norm_params)
 from .ops import Out
 from .roi_tables import ROI_INDICES, ROI_NAMES, ROI_INDEX_TO_NAME
 from .metrics import RoiCorrMetric, calc_roi_metrics          # noqa: F401  (:36-96, :1361-1397 of the reference module)
@@ -87,6 +87,21 @@ class ObservableAttentionBlock(nn.Module):
 
     def forward(self, g, x, out=None):
         cfg = self.cfg
+        if self.training and cfg.fused_gate:
+            # W_g / W_x: MFMA 1x1x1 convolutions with their BatchNorm statistics out of the epilogue; everything behind them
+            # (two BatchNorm applies, add, ReLU, psi dot product, its BatchNorm statistics, sigmoid, multiply) is two launches
+            # forward and three backward (ops.GateFused, csrc/gate.hip)
+            g1raw, sums_g = conv_plain(cfg, g, self.W_g[0].conv, 1, 1, False, None, L.NORM_BATCH)
+            x1raw, sums_x = conv_plain(cfg, x, self.W_x[0].conv, 1, 1, False, None, L.NORM_BATCH)
+            gg, bg, rmg, rvg, mom, eg = _norm_params(cfg, self.W_g[1], True)
+            gx, bx, rmx, rvx, _m, ex = _norm_params(cfg, self.W_x[1], True)
+            gp, bp, rmp, rvp, _m, ep = _norm_params(cfg, self.psi[1], True)
+            pc = self.psi[0].conv
+            att, psi = ops.GateFused.apply(x, g1raw, x1raw, sums_g, sums_x, gg, bg, gx, bx, pc.weight, pc.bias, gp, bp,
+                                           (rmg, rvg, rmx, rvx, rmp, rvp), mom, (eg, ex, ep), Out(out) if out is not None else None)
+            if self.save_attn:
+                return att, psi
+            return att
         g1 = conv_then_bn(cfg, g, self.W_g[0], self.W_g[1], L.ACT_NONE, self.training)
         x1 = conv_then_bn(cfg, x, self.W_x[0], self.W_x[1], L.ACT_NONE, self.training)
         s = ops.AddRelu.apply(g1, x1)
@@ -115,6 +130,11 @@ class AttentionLayer(nn.Module):
         self.attention.save_attn = status
 
     def forward(self, x, covariate=None):
+        # x feeds the next encoder block, the gate's W_x convolution and its final multiply; the up-convolution's output
+        # feeds W_g and the merge convolution: their data gradients meet in ONE buffer each (ops.GradFork) instead of being
+        # added pairwise by autograd
+        if self.cfg.grad_forks:
+            x = ops.fork(x)
         if isinstance(self.submodule, nn.Sequential):
             x_sub = x
             for sub in self.submodule:
@@ -132,6 +152,8 @@ class AttentionLayer(nn.Module):
         # torch.cat((att, fromlower), dim=1) of :229 -- both producers write their channel slice directly
         cat = torch.empty((B, D, H, W, 2 * C), dtype=x.dtype, device=x.device)
         fromlower = self.upconv(x_sub, covariate, out=cat[..., C:])
+        if self.cfg.grad_forks:
+            fromlower = ops.fork(fromlower)
         att = self.attention(g=fromlower, x=x, out=cat[..., :C])
         if self.save_attn is not None:
             att, _coeff = att   # the reference dumps coeff to disk here (data_util.save_attention_coeffs)

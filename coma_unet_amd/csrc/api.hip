@@ -41,7 +41,8 @@ bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const co
 bool conv_f32mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                   const coma_tensor* y, hipStream_t s, double2* stats = nullptr, int stats_inst = 0,
-                  int* stats_chunks = nullptr, void* ws = nullptr, size_t ws_bytes = 0, int ws_zeroed = 0);
+                  int* stats_chunks = nullptr, void* ws = nullptr, size_t ws_bytes = 0, int ws_zeroed = 0, int accum = 0);
+bool conv_mfma_accumulate_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 bool conv_mfma_wgrad_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
 size_t conv_mfma_wgrad_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy);
@@ -54,6 +55,11 @@ extern "C" int coma_conv_pick_algo(const coma_conv_desc* d, const coma_tensor* x
   if (conv_mfma_supported(d, x, y)) return 2;       // bf16 tensors: MFMA wherever the shape allows
   if (conv_f32mfma_supported(d, x, y)) return 3;    // fp32 tensors: fp32 MFMA wherever the shape allows
   return 1;
+}
+
+extern "C" int coma_conv_accumulate_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  const int algo = coma_conv_pick_algo(d, x, y);
+  return algo >= 2 && conv_mfma_accumulate_ok(d, x, y) ? 1 : 0;
 }
 
 extern "C" size_t coma_conv_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
@@ -70,17 +76,18 @@ extern "C" int coma_conv_fwd_ws(const coma_conv_desc* d, const coma_tensor* x, c
                                 void* stream) {
   if (int rc = conv_check(d, x, y)) return rc;
   COMA_CHECK(wk, "conv_fwd: null weights");
-  const int wz = (zeroed & COMA_ZEROED_WS) ? 1 : 0;
+  const int wz = (zeroed & COMA_ZEROED_WS) ? 1 : 0, accum = (zeroed & COMA_ACCUMULATE) ? 1 : 0;
+  COMA_CHECK(!accum || coma_conv_accumulate_ok(d, x, y), "conv_fwd: COMA_ACCUMULATE is not supported for this problem (ask coma_conv_accumulate_ok)");
   hipStream_t s = (hipStream_t)stream;
   const int algo = coma_conv_pick_algo(d, x, y);
   if (algo == 2) {
     COMA_CHECK(wk_dtype == COMA_BF16, "conv_fwd: MFMA path needs bf16 kernel-layout weights");
     COMA_CHECK(conv_mfma_supported(d, x, y), "conv_fwd: shape not supported by the MFMA path (C=%d N=%d dtype=%d)",
                x->C, y->C, x->dtype);
-    return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes, wz);
+    return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes, wz, accum);
   }
   COMA_CHECK(wk_dtype == COMA_F32, "conv_fwd: fp32 tensors need fp32 kernel-layout weights");
-  if (algo == 3) return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes, wz);
+  if (algo == 3) return conv_mfma_fwd(d, x, wk, bias, y, s, nullptr, 0, nullptr, ws, ws_bytes, wz, accum);
   if (conv_point1_ok(d, x, y)) return conv_point1_fwd(d, x, (const float*)wk, bias, y, s);
   return conv_direct_fwd(d, x, (const float*)wk, bias, y, s);
 }

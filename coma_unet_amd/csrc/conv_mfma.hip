@@ -45,6 +45,7 @@ struct GatherP {
   int Mz, My, Mx;                      // M-grid (MODE 0: output grid; MODE 1: coarse grid)
   int ksplit;                          // > 1: the K loop (taps x channel chunks) is cut into ksplit slices on blockIdx.y
   float* part; long part_sb;           //      whose fp32 partial tiles are merged atomically into part[b][voxel][N]
+  int accum;                           // y += conv(x) instead of y = conv(x) (a data gradient added to one that is already there)
 };
 
 // fused norm statistics: a block ADDS its {sum, sumsq} of one (group, channel) to the caller's zeroed fp64 record
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
         const int off = rowoff[row];
         if (off >= 0) {
           if (p.ksplit > 1) atomicAdd(p.part + (long)b * p.part_sb + (long)(off / p.ldy) * p.N + n, acc[i][j][e]);
-          else yb[off + n] = static_cast<T>(acc[i][j][e] + bv);
+          else yb[off + n] = static_cast<T>(acc[i][j][e] + bv + (p.accum ? static_cast<float>(yb[off + n]) : 0.f));
         }
       }
     }
@@ -257,12 +258,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
 // y[v][n] = T(part[v][n] + bias[n])  (the merge of the split-K partials)
 template <typename T>
 __global__ __launch_bounds__(256) void gather_finalize_k(const float* __restrict__ part, long part_sb, T* __restrict__ y, int ldy,
-                                                         long sby, int N, long V, const float* __restrict__ bias, int bsb) {
+                                                         long sby, int N, long V, const float* __restrict__ bias, int bsb, int accum) {
   const int b = blockIdx.y;
   const long total = V * N;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long v = e / N; const int n = (int)(e - v * N);
-    y[(long)b * sby + v * ldy + n] = static_cast<T>(part[(long)b * part_sb + e] + (bias ? bias[b * bsb + n] : 0.f));
+    T* dst = y + (long)b * sby + v * ldy + n;
+    *dst = static_cast<T>(part[(long)b * part_sb + e] + (bias ? bias[b * bsb + n] : 0.f) + (accum ? static_cast<float>(*dst) : 0.f));
   }
 }
 
@@ -1530,6 +1532,7 @@ struct PwP {
   int st8;
   double2* stats;      // optional fused {sum, sumsq} partials of the stored outputs, [chunk][G][N] (as conv_mfma_halo2_k)
   int stats_inst;
+  int accum;           // y += conv(x)
 };
 
 template <int KS, int NT>   // KS = ceil(C / 16) K steps, NT = ceil(N / 32) row tiles
@@ -1594,9 +1597,20 @@ __global__ __launch_bounds__(256) void conv_mfma_pw_k(PwP p) {
         for (int g4 = 0; g4 < 4; ++g4) {
           if (j * 32 + 8 * g4 >= p.N) continue;          // (wave-uniform) zero-padded channel groups: nothing to convert or sum
           bf16_t o[4];
+          float old[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.accum) {                                  // (wave-uniform) y += : read what is there
+            if (p.st8 && j * 32 + 8 * g4 + 4 * fh + 3 < p.N) {
+              const uint2 u = *reinterpret_cast<const uint2*>(dst + 8 * g4);
+              old[0] = __uint_as_float(u.x << 16); old[1] = __uint_as_float(u.x & 0xffff0000u);
+              old[2] = __uint_as_float(u.y << 16); old[3] = __uint_as_float(u.y & 0xffff0000u);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (j * 32 + 8 * g4 + 4 * fh + q < p.N) old[q] = static_cast<float>(dst[8 * g4 + q]);
+            }
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            o[q] = static_cast<bf16_t>(acc[g4 * 4 + q] + bv[j][g4][q]);
+            o[q] = static_cast<bf16_t>(acc[g4 * 4 + q] + bv[j][g4][q] + old[q]);
             if (do_stats) {
               const float r = static_cast<float>(o[q]);
               st_s[j][g4][q] += r; st_q[j][g4][q] = fmaf(r, r, st_q[j][g4][q]);
@@ -1728,7 +1742,7 @@ static int launch_gather(const GatherP& p0, int mode, int B, hipStream_t s, void
     long nb = (Vout * p.N + 255) / 256;
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(gather_finalize_k<T>, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, (const float*)p.part, p.part_sb, (T*)p.y, p.ldy,
-                       p.sby, p.N, Vout, p.bias, p.bsb);
+                       p.sby, p.N, Vout, p.bias, p.bsb, p.accum);
     COMA_LAUNCH_CHECK();
   }
   return 0;
@@ -1875,6 +1889,13 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
 }
 
 // bytes of workspace with which the deep layers' K loop may be split over more blocks (0: never split)
+// y += conv(x) is implemented by the gather and pointwise kernels (the data gradients that land on an activation other
+// consumers also feed: strided / transposed / 1x1x1 layers), not by the halo-tiled stride-1 kernels
+bool conv_mfma_accumulate_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  if (x->dtype == COMA_F32) return conv_f32mfma_supported(d, x, y) && !thin16f_ok(d, x, y) && !f32_halo_ok(d, x, y);
+  return conv_mfma_supported(d, x, y) && !halo_ok(d, x, y);
+}
+
 static int gather_ksplit(long blocks, int nsteps, bool f32);
 size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (x->dtype == COMA_F32) { if (thin16f_ok(d, x, y) || f32_halo_ok(d, x, y)) return 0; }
@@ -1894,8 +1915,9 @@ size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, con
 
 int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                   const coma_tensor* y, hipStream_t s, double2* stats, int stats_inst, int* stats_chunks, void* ws,
-                  size_t ws_bytes, int ws_zeroed) {
+                  size_t ws_bytes, int ws_zeroed, int accum) {
   const bool f32 = x->dtype == COMA_F32;
+  COMA_CHECK(!accum || conv_mfma_accumulate_ok(d, x, y), "conv_mfma: this problem's kernel family cannot accumulate into y");
   if (f32 && thin16f_ok(d, x, y)) return conv_thin16f(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
   if (f32) { if (f32_halo_ok(d, x, y)) return conv_mfma_halo<float>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks); }
   else if (halo_ok(d, x, y)) return conv_mfma_halo<bf16_t>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
@@ -1910,7 +1932,7 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
     const int ks = (x->C + 15) / 16, nt = (y->C + 31) / 32;
     long nb = ((q.V + 31) / 32 + 3) / 4;
     if (nb > 2048) nb = 2048;
-    q.stats = nullptr; q.stats_inst = stats_inst;
+    q.stats = nullptr; q.stats_inst = stats_inst; q.accum = accum;
     if (stats) { q.stats = stats; *stats_chunks = 1; }
     dim3 grid((unsigned)nb, (unsigned)x->B);
     coma_set_kernel_tag("conv_mfma_pw_k<%d, %d>", ks > 4 ? 4 : ks, nt);
@@ -1928,7 +1950,7 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
   const int taps = d->ksize * d->ksize * d->ksize;
   p.w = wk; p.wsb = d->per_sample_w ? (long)taps * y->C * x->C : 0;
   p.bias = bias; p.bsb = d->per_sample_w ? y->C : 0;
-  p.k = d->ksize; p.stride = d->stride; p.flip = 0;
+  p.k = d->ksize; p.stride = d->stride; p.flip = 0; p.accum = accum;
   int mode = 0;
   if (d->form == 1 && d->stride == 1) { p.flip = 1; }
   if (d->form == 1 && d->stride == 2) {

@@ -187,35 +187,39 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
       ga[j] = gamma ? gamma[c] : 1.f; be[j] = gamma ? beta[c] : 0.f;
     }
     // bf16: fp32 partial sums over bursts of 8 rows folded into fp64; fp32: every term straight to fp64 -- see
-    // stats_partial_k.  The loads of a burst (two tensors) are issued together.
-    constexpr int BURST = sizeof(T) == 2 ? 8 : 4;
+    // stats_partial_k.  Two rows (of both tensors) are in flight per lane: more costs registers, and with them the
+    // occupancy a streaming kernel lives on (8 rows at once: 188 VGPRs, 2 waves per SIMD, half the bandwidth).
+    constexpr int BURST = sizeof(T) == 2 ? 8 : 2, LD = 2;
     RowWalk w(p, r0 + ty);
     while (w.r < r1) {
-      float xv[BURST][VEC], dv[BURST][VEC];
-      bool ok[BURST];
-      int64_t lx = w.off(p, g, p.ld, p.sb), ldd = w.off(p, g, lddy, sbdy);
-#pragma unroll
-      for (int u = 0; u < BURST; ++u) {
-        ok[u] = w.r < r1;
-        if (ok[u]) { lx = w.off(p, g, p.ld, p.sb); ldd = w.off(p, g, lddy, sbdy); }
-        vec_io<T, VEC>::load(xb + lx + tx * VEC, xv[u]);
-        vec_io<T, VEC>::load(dyb + ldd + tx * VEC, dv[u]);
-        w.step(p);
-      }
       float f1[VEC], f2[VEC], f3[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { f1[j] = 0.f; f2[j] = 0.f; f3[j] = 0.f; }
+#pragma unroll 1
+      for (int h = 0; h < BURST / LD; ++h) {      // (not unrolled: the compiler would hoist all 8 rows' loads to the top)
+        float xv[LD][VEC], dv[LD][VEC];
+        bool ok[LD];
+        int64_t lx = w.off(p, g, p.ld, p.sb), ldd = w.off(p, g, lddy, sbdy);
 #pragma unroll
-      for (int u = 0; u < BURST; ++u) {
+        for (int u = 0; u < LD; ++u) {
+          ok[u] = w.r < r1;
+          if (ok[u]) { lx = w.off(p, g, p.ld, p.sb); ldd = w.off(p, g, lddy, sbdy); }
+          vec_io<T, VEC>::load(xb + lx + tx * VEC, xv[u]);
+          vec_io<T, VEC>::load(dyb + ldd + tx * VEC, dv[u]);
+          w.step(p);
+        }
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const float xh = (xv[u][j] - mu[j]) * rs[j];
-          const float z = xh * ga[j] + be[j];
-          float ds; const float da = act_bwd(act, z, a, &ds);
-          const float dvv = ok[u] ? dv[u][j] : 0.f;
-          const float dz = dvv * da;
-          if (sizeof(T) == 2) { f1[j] += dz; f2[j] = fmaf(dz, xh, f2[j]); f3[j] = fmaf(dvv, ds, f3[j]); }
-          else { s1[j] += (double)dz; s2[j] += (double)(dz * xh); s3[j] += (double)(dvv * ds); }
+        for (int u = 0; u < LD; ++u) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float xh = (xv[u][j] - mu[j]) * rs[j];
+            const float z = xh * ga[j] + be[j];
+            float ds; const float da = act_bwd(act, z, a, &ds);
+            const float dvv = ok[u] ? dv[u][j] : 0.f;
+            const float dz = dvv * da;
+            if (sizeof(T) == 2) { f1[j] += dz; f2[j] = fmaf(dz, xh, f2[j]); f3[j] = fmaf(dvv, ds, f3[j]); }
+            else { s1[j] += (double)dz; s2[j] += (double)(dz * xh); s3[j] += (double)(dvv * ds); }
+          }
         }
       }
       if (sizeof(T) == 2) {

@@ -30,6 +30,12 @@ class Config:
         self.conv_algo = conv_algo            # 0 auto, 1 direct VALU fp32, 2 MFMA bf16
         self.bn_updates_per_forward = bn_updates_per_forward
         self.nbt_pending = None               # list while a model forward collects BatchNorm step counters
+        # round 3: the attention gate behind its 1x1x1 convolutions as two fused kernels each way (ops.GateFused) and shared
+        # gradient buffers for activations with several consumers (ops.GradFork); COMA_FUSED_GATE=0 / COMA_GRAD_FORKS=0
+        # restore the piecewise path (A/B measurements, and the reference composition for the tests)
+        import os
+        self.fused_gate = os.environ.get("COMA_FUSED_GATE", "1") not in ("0", "")
+        self.grad_forks = os.environ.get("COMA_GRAD_FORKS", "1") not in ("0", "")
 
     def begin_forward(self):
         self.nbt_pending = []

@@ -240,6 +240,55 @@ class GradSink:
         return cls.slots((p,))[0]
 
 
+class GradFork:
+    """Gradient meeting point of an activation with several consumers (a skip connection: the next encoder block, the gate's
+    W_x convolution and its final multiply; the up-convolution's output: W_g and the merge convolution).  Autograd would
+    give every consumer its own gradient tensor and add them pairwise (an ATen pass of 3 tensor volumes per extra
+    consumer: 0.6 ms per 128^3 step).  Here the first consumer's backward kernel WRITES the shared buffer and the later
+    ones ACCUMULATE into it in their epilogues (COMA_ACCUMULATE, gate_apply_bwd's accumulate flag); they hand autograd
+    ``None``, and ``Fork.backward`` returns the buffer.  A consumer whose kernel cannot accumulate simply returns its
+    gradient the ordinary way and ``Fork.backward`` adds it -- correct in any mix and any order."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+    def offer(self, t):
+        """A consumer that already holds its gradient as a tensor (a channel slice of the concat buffer's gradient): it
+        becomes the shared buffer if there is none yet.  True: taken (hand autograd None)."""
+        if self.buf is None:
+            self.buf = t
+            return True
+        return False
+
+
+class Fork(Function):
+    @staticmethod
+    def forward(ctx, x, fork):
+        ctx.set_materialize_grads(False)
+        ctx.fork = fork
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf, ctx.fork.buf = ctx.fork.buf, None
+        if buf is None:
+            return g, None
+        if g is None:
+            return buf, None
+        return buf + g, None
+
+
+def fork(x):
+    """x with a gradient meeting point attached (see GradFork); x itself when no gradient will flow."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x
+    f = GradFork()
+    y = Fork.apply(x, f)
+    y._coma_fork = f
+    return y
+
+
 class SidePrep:
     """Weight preparation off the critical path.  Routing, the expert mix / re-layout of the masters and (backward) the
     scatter of the kernel-layout weight gradient to the experts depend on parameters and covariates only, never on an
@@ -503,23 +552,34 @@ def _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm):
     return y, sums
 
 
-def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_dx, need_dw, bias_mode, p_bias):
+def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_dx, need_dw, bias_mode, p_bias, fork=None):
     """-> dx, dwk (fp32, kernel layout), dbias (None when absent, written through, or identically zero).
     bias_mode: 0 no bias, 1 reduce dy over the voxels, 2 the bias feeds a mean-removing normalisation (its gradient is
-    identically zero: exact zeros are returned instead of a reduction of rounding noise)."""
+    identically zero: exact zeros are returned instead of a reduction of rounding noise).
+    fork: the input's GradFork -- the data gradient is written / accumulated into the shared buffer and dx is None."""
     dx = dwk = dbias = None
     s = L.stream()
     tag = (tuple(x.shape), dy.shape[4], ksize, stride, form)
     if need_dx:
         assert wk_d is not None, "data gradient requested but dgrad weights were not prepared"
-        dx = _new(x.shape, x.dtype, x.device)
-        dd, cdy_, cdx = _desc(ksize, stride, 1 - form, per_sample, algo), ct(dy), ct(dx)
+        dd, cdy_ = _desc(ksize, stride, 1 - form, per_sample, algo), ct(dy)
+        flags, shared = 0, False
+        if fork is not None and fork.buf is None:
+            dx = fork.buf = _new(x.shape, x.dtype, x.device)        # first consumer: "="
+            shared = True
+        elif fork is not None and lib.coma_conv_accumulate_ok(dd, cdy_, ct(fork.buf)):
+            dx, flags, shared = fork.buf, L.ACCUMULATE, True         # later consumer: "+=" in the kernel's epilogue
+        else:
+            dx = _new(x.shape, x.dtype, x.device)
+        cdx = ct(dx)
         wsd, zfd = _scratch(lib.coma_conv_fwd_ws_bytes(dd, cdy_, cdx), x.device)
         KernelTimer.run("conv_dgrad", conv_class(_ALGO_NAMES[lib.coma_conv_pick_algo(dd, cdy_, cdx)] if KernelTimer.enabled else "",
                                                    dy.shape[4], x.shape[4]),
                         conv_flops(dy.shape, dx.shape, ksize, stride),
                         lambda: check(lib.coma_conv_fwd_ws(dd, cdy_, ptr(wk_d), L.dtype_code(wk_d.dtype), None, cdx, ptr(wsd),
-                                                           wsd.numel(), zfd, s), "coma_conv_fwd(dgrad)"), tag=tag)
+                                                           wsd.numel(), zfd | flags, s), "coma_conv_fwd(dgrad)"), tag=tag)
+        if shared:
+            dx = None
     if need_dw:
         d = _desc(ksize, stride, form, per_sample, algo)
         cx, cdy = ct(x), ct(dy)
@@ -612,6 +672,7 @@ class ConvLayer(Function):
             wk_f, wk_d, rr, pmeta = _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype)
         y, sums = _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm)
         ctx.save_for_backward(x, wk_d, master, rr)
+        ctx.fork = getattr(x, "_coma_fork", None)
         ctx.side = side
         if side and any(ctx.needs_input_grad):
             SidePrep._live += 1
@@ -633,7 +694,7 @@ class ConvLayer(Function):
         ksize, stride, form, per_sample, algo, bias_mode, wshape, pmeta = ctx.meta
         need_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dx, dwk, dbias = _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, ctx.needs_input_grad[0],
-                                   need_dw, bias_mode, ctx.p_bias)
+                                   need_dw, bias_mode, ctx.p_bias, ctx.fork)
         dmaster = dr = None
         if ctx.side:
             SidePrep._live = max(0, SidePrep._live - 1)
@@ -747,20 +808,105 @@ class GateMul(Function):
         return dx, dpsi, None
 
 
+class GateFused(Function):
+    """The attention gate behind its W_g / W_x convolutions (csrc/gate.hip; attn_unet_data_parallel.py:139-150), training mode:
+        s = relu(BN_g(g1raw) + BN_x(x1raw));  psi = sigmoid(BN_psi(w_psi . s + b_psi));  att = x * psi
+    two launches forward, three backward.  Returns (att, psi); psi is for inspection only (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, x, g1raw, x1raw, sums_g, sums_x, gam_g, bet_g, gam_x, bet_x, w_psi, b_psi, gam_p, bet_p,
+                running, momentum, eps, out):
+        ctx.set_materialize_grads(False)
+        dev, dt = x.device, x.dtype
+        B, D, H, W, C = x.shape
+        F_ = g1raw.shape[4]
+        rm_g, rv_g, rm_x, rv_x, rm_p, rv_p = running if running is not None else (None,) * 6
+        eps_g, eps_x, eps_p = eps
+        s_t = _new((B, D, H, W, F_), dt, dev)
+        psi_raw = _new((B, D, H, W, 1), dt, dev)
+        psi = _new((B, D, H, W, 1), dt, dev)
+        sums_p = stat_record(1, 1, 2, dev)
+        st = L.stream()
+        wv = w_psi.reshape(-1)
+        assert wv.is_contiguous() and wv.dtype == torch.float32 and wv.numel() == F_
+        check(lib.coma_gate_mid_fwd(ct(g1raw), ct(x1raw), ptr(sums_g), eps_g, ptr(gam_g), ptr(bet_g), ptr(sums_x), eps_x,
+                                    ptr(gam_x), ptr(bet_x), ptr(wv), ptr(b_psi), ptr(rm_g), ptr(rv_g), ptr(rm_x), ptr(rv_x),
+                                    momentum, ct(s_t), ct(psi_raw), ptr(sums_p), st), "coma_gate_mid_fwd")
+        att = out.t if out is not None else _new(x.shape, dt, dev)
+        check(lib.coma_gate_apply_fwd(ct(x), ct(psi_raw), ptr(sums_p), eps_p, ptr(gam_p), ptr(bet_p), ptr(rm_p), ptr(rv_p),
+                                      momentum, ct(psi), ct(att), st), "coma_gate_apply_fwd")
+        ctx.save_for_backward(x, g1raw, x1raw, s_t, psi_raw, psi, sums_g, sums_x, sums_p, gam_g, gam_x, gam_p, bet_p, wv)
+        ctx.params = (gam_g, bet_g, gam_x, bet_x, w_psi, gam_p, bet_p)
+        ctx.b_psi = b_psi
+        ctx.eps = eps
+        ctx.fork = getattr(x, "_coma_fork", None)
+        ctx.mark_non_differentiable(psi)
+        return att, psi
+
+    @staticmethod
+    def backward(ctx, datt, _dpsi):
+        n_in = 17
+        if datt is None:
+            return (None,) * n_in
+        x, g1raw, x1raw, s_t, psi_raw, psi, sums_g, sums_x, sums_p, gam_g, gam_x, gam_p, bet_p, wv = ctx.saved_tensors
+        eps_g, eps_x, eps_p = ctx.eps
+        dev, dt = x.device, x.dtype
+        B, D, H, W, C = x.shape
+        F_ = g1raw.shape[4]
+        st = L.stream()
+        fork = ctx.fork
+        if fork is not None and fork.buf is not None:
+            dx, acc, shared = fork.buf, 1, True
+        else:
+            dx, acc, shared = _new(x.shape, dt, dev), 0, fork is not None
+            if shared:
+                fork.buf = dx
+        dz = _new((B, D, H, W, 1), dt, dev)
+        bs_p = stat_record(1, 1, 3, dev)
+        check(lib.coma_gate_apply_bwd(ct(x), ct(psi), ct(psi_raw), ct(datt), ptr(sums_p), eps_p, ptr(gam_p), ptr(bet_p),
+                                      ct(dx), acc, ct(dz), ptr(bs_p), st), "coma_gate_apply_bwd")
+        sinks = GradSink.slots(ctx.params)          # one kernel writes all seven: one flush, then the marks
+        fresh = lambda i, n: sinks[i] if sinks[i] is not None else _f32(n, dev)
+        dgg, dbg, dgx, dbx = fresh(0, F_), fresh(1, F_), fresh(2, F_), fresh(3, F_)
+        dw, dgp, dbp = fresh(4, F_), fresh(5, 1), fresh(6, 1)
+        rec = stat_record(1, F_, 4, dev)
+        dg1 = _new(g1raw.shape, dt, dev)
+        dx1 = _new(x1raw.shape, dt, dev)
+        check(lib.coma_gate_mid_bwd(ct(dz), ct(psi_raw), ct(s_t), ct(g1raw), ct(x1raw), ptr(sums_p), eps_p, ptr(gam_p), ptr(bs_p),
+                                    ptr(sums_g), eps_g, ptr(gam_g), ptr(sums_x), eps_x, ptr(gam_x), ptr(wv), ptr(rec),
+                                    ct(dg1), ct(dx1), ptr(dgg), ptr(dbg), ptr(dgx), ptr(dbx), ptr(dw), ptr(dgp), ptr(dbp), st),
+              "coma_gate_mid_bwd")
+        ret = lambda i, t: None if sinks[i] is not None else t
+        # the psi convolution's bias is removed again by BN_psi: its gradient is identically zero (exact zeros, as for every
+        # convolution bias under a normalisation: layers.Config.zero_bias_grad_under_norm)
+        db_psi = None
+        if ctx.b_psi is not None and GradSink.slot(ctx.b_psi) is None:
+            db_psi = torch.zeros_like(ctx.b_psi)
+        w_shape = ctx.params[4].shape
+        return (None if shared else dx, dg1, dx1, None, None, ret(0, dgg), ret(1, dbg), ret(2, dgx), ret(3, dbx),
+                ret(4, dw.view(w_shape)), db_psi, ret(5, dgp), ret(6, dbp), None, None, None, None)
+
+
 class JoinSlices(Function):
     """The parts were written straight into channel slices of `buf`; hand the whole buffer on.
-    Backward hands each producer its slice of the buffer's gradient (no copy either way)."""
+    Backward hands each producer its slice of the buffer's gradient (no copy either way); a part with a GradFork gets its
+    slice installed as the fork's shared buffer, so that its other consumers accumulate straight into it."""
 
     @staticmethod
     def forward(ctx, buf_holder, *parts):
+        ctx.set_materialize_grads(False)
         ctx.widths = [p.shape[4] for p in parts]
+        ctx.forks = [getattr(p, "_coma_fork", None) for p in parts]
         return buf_holder.t
 
     @staticmethod
     def backward(ctx, dbuf):
+        if dbuf is None:
+            return (None,) * (1 + len(ctx.widths))
         outs, c0 = [], 0
-        for w in ctx.widths:
-            outs.append(dbuf[..., c0:c0 + w])
+        for w, f in zip(ctx.widths, ctx.forks):
+            sl = dbuf[..., c0:c0 + w]
+            outs.append(None if (f is not None and f.offer(sl)) else sl)
             c0 += w
         return (None, *outs)
 

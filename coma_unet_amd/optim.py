@@ -114,7 +114,6 @@ class FusedAdamW(torch.optim.Optimizer):
         gradients arrive (GradReducer.reduce_flat_and_step): advance=True on the first call only (the step count moves
         once), loose=True on one call only (parameters outside the flat buffer)."""
         ops.SidePrep.join()       # the side stream's expert-gradient scatters land in the flat gradient buffer
-        ops.ZeroArena.end_step()  # backward is over: every slice of the step's zeroed arena is dead -- one memset clears them
         g = self.param_groups[0]
         lr, (b1, b2), eps, wd = float(g["lr"]), g["betas"], g["eps"], g["weight_decay"]
         if not self.built:
@@ -129,6 +128,10 @@ class FusedAdamW(torch.optim.Optimizer):
                            lr, b1, b2, eps, wd, self._flat_step, self._step_dev)
         if not loose:
             return
+        # backward is over: every slice of the step's zeroed arena is dead -- ONE memset clears them.  Behind the AdamW launch,
+        # not in front of it: with ~170 MB of freshly dirtied lines ahead of it the 2.7 GB AdamW sweep measured 1.10 ms
+        # instead of 0.85 ms.
+        ops.ZeroArena.end_step()
         for p in g["params"]:
             if id(p) in self._flat_ids or p.grad is None:
                 continue

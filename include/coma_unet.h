@@ -50,7 +50,11 @@ enum { COMA_F32 = 0, COMA_BF16 = 1 };
  * memset.  A training step keeps ONE zeroed arena and hands out slices of it (~60 memset launches per step gone).
  * COMA_ZEROED_OUT: the output the call accumulates into (dwk / dr); COMA_ZEROED_WS: the first *_ws_bytes() bytes of
  * `ws`, which must then be private to this call (the callee leaves them dirty).  0 = the callee zeroes what it needs. */
-enum { COMA_ZEROED_OUT = 1, COMA_ZEROED_WS = 2 };
+enum { COMA_ZEROED_OUT = 1, COMA_ZEROED_WS = 2,
+       /* coma_conv_fwd_ws only: y += conv(x) instead of y = conv(x) -- a data gradient added to the gradient another
+        * consumer of the same activation has already written (no separate accumulation pass); valid where
+        * coma_conv_accumulate_ok() answers 1 (the gather / pointwise kernel families)                                */
+       COMA_ACCUMULATE = 4 };
 
 /* activation after a normalisation (MONAI ADN "A" slot) */
 enum {
@@ -138,6 +142,7 @@ int coma_conv_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
  * split their K loop (taps x channel chunks) over more blocks, merge fp32 partials in `ws` and convert once.
  * ws_bytes >= coma_conv_fwd_ws_bytes(...) enables it; a smaller or NULL ws runs the unsplit kernel.          */
 size_t coma_conv_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
+int coma_conv_accumulate_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y);
 int coma_conv_fwd_ws(const coma_conv_desc* d, const coma_tensor* x, const void* wk, int32_t wk_dtype,
                      const float* bias, const coma_tensor* y, void* ws, size_t ws_bytes, int32_t zeroed, void* stream);
 /* conv forward + statistics of the BatchNorm(train)/InstanceNorm that follows it (MONAI Convolution =

@@ -762,3 +762,102 @@ def test_thin16f_kernel_fp32_fwd_dgrad_and_fused_stats(case, mode):
         if not per_sample:
             gw = gw.sum(0, keepdim=True)
         assert torch.isfinite(dwk).all() and rel(dwk, gw) < 2e-5, rel(dwk, gw)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [32, 64, 256])
+def test_fused_gate_block_matches_torch(C, dtype):
+    """ObservableAttentionBlock in training mode = ops.GateFused (csrc/gate.hip: two launches forward, three backward)
+    behind the W_g / W_x MFMA convolutions, against the fp64 torch composition of MONAI's AttentionBlock
+    (attn_unet_data_parallel.py:139-150): output, psi, every input and parameter gradient, the running statistics; the
+    gate output is written into a channel slice of a wider buffer and x carries a GradFork with a second consumer (the
+    gate's dx must then ACCUMULATE into the shared buffer)."""
+    ops, L = _ops()
+    from coma_unet_amd.attn_unet_data_parallel import ObservableAttentionBlock
+    from coma_unet_amd.layers import Config
+    torch.manual_seed(C)
+    Fi = C // 2
+    B, dims = 2, (4, 6, 8)
+    blk = ObservableAttentionBlock(Config(compute_dtype=dtype), f_int=Fi, f_g=C, f_l=C).cuda()
+    blk.train()
+    blk.save_attn = True
+    with torch.no_grad():
+        for bn in (blk.W_g[1], blk.W_x[1], blk.psi[1]):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(C + 1)
+    mk = lambda c: torch.randn((B, c, *dims), generator=g, dtype=torch.float64).to(dtype).double()
+    gq, xq, gy, gy2 = mk(C), mk(C), mk(C), mk(C)
+    # ---- fp64 reference
+    P = {k: v.detach().double().cpu().clone().requires_grad_(True) for k, v in blk.named_parameters()}
+    gr, xr = gq.clone().requires_grad_(True), xq.clone().requires_grad_(True)
+    rm = {n: [torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)] for n, c in (("W_g", Fi), ("W_x", Fi), ("psi", 1))}
+
+    def cbn(name, t):
+        y = F.conv3d(t, P[f"{name}.0.conv.weight"], P[f"{name}.0.conv.bias"])
+        return F.batch_norm(y, rm[name][0], rm[name][1], P[f"{name}.1.weight"], P[f"{name}.1.bias"], True, 0.1, 1e-5)
+
+    s_r = F.relu(cbn("W_g", gr) + cbn("W_x", xr))
+    psi_r = torch.sigmoid(cbn("psi", s_r))
+    att_r = xr * psi_r
+    ((att_r * gy).sum() + (xr * gy2).sum()).backward()          # (second consumer of x: a plain weighted sum)
+    # ---- HIP
+    dev = "cuda"
+    gi = to_int(gq).to(dev, dtype).requires_grad_(True)
+    xi = to_int(xq).to(dev, dtype).requires_grad_(True)
+    xf = ops.fork(xi)
+    cat = torch.zeros((B, *dims, 2 * C), device=dev, dtype=dtype)
+    att, psi = blk(gi, xf, out=cat[..., :C])
+    assert L.lib.coma_last_kernel() is not None
+    other = ops.GateMul.apply(xf, torch.ones((B, *dims, 1), device=dev, dtype=dtype), None)     # second consumer of the fork
+    tol = TOL[dtype]
+    assert rel(to_ext(att), att_r) < tol and rel(to_ext(psi), psi_r) < tol
+    assert float(cat[..., C:].abs().max()) == 0.0
+    torch.autograd.backward([att, other], [to_int(gy).to(dev, dtype), to_int(gy2).to(dev, dtype)])
+    gt = 4 * tol
+    assert rel(to_ext(gi.grad), gr.grad) < gt, rel(to_ext(gi.grad), gr.grad)
+    assert rel(to_ext(xi.grad), xr.grad) < gt, rel(to_ext(xi.grad), xr.grad)
+    for k, v in blk.named_parameters():
+        if k.endswith("0.conv.bias"):          # removed by the BatchNorm behind it: exact zeros here, rounding noise in torch
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+            continue
+        assert v.grad is not None, k
+        assert rel(v.grad, P[k].grad) < gt, (k, rel(v.grad, P[k].grad))
+    for name in ("W_g", "W_x", "psi"):
+        bn = getattr(blk, name)[1]
+        assert rel(bn.running_mean, rm[name][0]) < 10 * tol and rel(bn.running_var, rm[name][1]) < 10 * tol, name
+        assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grad_fork_accumulates_in_kernel_epilogues(dtype):
+    """ops.GradFork: three consumers of one activation -- a 1x1x1 convolution (pointwise / gather kernel: COMA_ACCUMULATE),
+    a stride-2 3x3x3 convolution (gather kernel) and a 3x3x3 stride-1 convolution (halo kernel: cannot accumulate, returns
+    its gradient the ordinary way) -- must give the sum of the three data gradients, whatever order autograd runs them in."""
+    ops, L = _ops()
+    from coma_unet_amd.layers import Config, Convolution
+    torch.manual_seed(3)
+    C, B, dims = 32, 2, (8, 8, 32)
+    cfg = Config(compute_dtype=dtype)
+    convs = [Convolution(cfg, C, 16, kernel_size=1, conv_only=True).cuda(), Convolution(cfg, C, 64, strides=2, conv_only=True).cuda(),
+             Convolution(cfg, C, 32, conv_only=True).cuda()]
+    g = torch.Generator().manual_seed(5)
+    xq = torch.randn((B, C, *dims), generator=g, dtype=torch.float64).to(dtype).double()
+    xr = xq.clone().requires_grad_(True)
+    tot = 0.0
+    gys = []
+    for cv in convs:
+        w, b = cv.conv.weight.detach().double().cpu(), cv.conv.bias.detach().double().cpu()
+        if dtype == torch.bfloat16:
+            w = w.bfloat16().double()
+        y = F.conv3d(xr, w, b, stride=cv.s, padding=(cv.k - 1) // 2)
+        gys.append(torch.randn(y.shape, generator=g, dtype=torch.float64).to(dtype).double())
+        tot = tot + (y * gys[-1]).sum()
+    tot.backward()
+    xi = to_int(xq).to("cuda", dtype).requires_grad_(True)
+    xf = ops.fork(xi)
+    assert getattr(xf, "_coma_fork", None) is not None
+    outs = [cv(xf) for cv in convs]
+    torch.autograd.backward(outs, [to_int(t).to("cuda", dtype) for t in gys])
+    assert rel(to_ext(xi.grad), xr.grad) < 3 * TOL[dtype], rel(to_ext(xi.grad), xr.grad)
+    assert xf._coma_fork.buf is None          # the meeting point was handed back
