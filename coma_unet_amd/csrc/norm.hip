@@ -195,11 +195,13 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(RowsP p, const void* d
       float f1[VEC], f2[VEC], f3[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { f1[j] = 0.f; f2[j] = 0.f; f3[j] = 0.f; }
+      // offsets of the last VALID row: a row past the chunk re-reads it (masked) -- computed here, where w.r < r1 holds; the
+      // walk itself may step past the tensor (sample index B) and its offsets must never be dereferenced then
+      int64_t lx = w.off(p, g, p.ld, p.sb), ldd = w.off(p, g, lddy, sbdy);
 #pragma unroll 1
       for (int h = 0; h < BURST / LD; ++h) {      // (not unrolled: the compiler would hoist all 8 rows' loads to the top)
         float xv[LD][VEC], dv[LD][VEC];
         bool ok[LD];
-        int64_t lx = w.off(p, g, p.ld, p.sb), ldd = w.off(p, g, lddy, sbdy);
 #pragma unroll
         for (int u = 0; u < LD; ++u) {
           ok[u] = w.r < r1;
