@@ -1665,6 +1665,373 @@ static bool pw_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tens
          x->ld % 8 == 0 && x->sb % 8 == 0 && (!x->data || aligned16(x->data)) && t_vox(x) >= 4096;
 }
 
+
+// =====================================================================================
+// conv_mfma_tconv_k -- stride-2 3x3x3 TRANSPOSED convolution (the up-convolutions, attn_unet_data_parallel.py:120-131,223)
+// and the data-gradient of the stride-2 encoder convolutions (:318-325), coarse width >= 32, with the COARSE halo staged
+// once per channel chunk in LDS (round 3; these layers ran on conv_mfma_gather_k: every K step re-gathered from global,
+// 3.0x its algorithmic HBM bytes, 8 % of the bf16 peak).
+//   out[2m + p] = sum over taps t with (2m + p + 1 - t) even of x[(2m + p + 1 - t) / 2] w[t], per dimension:
+//     p = 0: tap 1 at x[m];   p = 1: tap 0 at x[m + 1] and tap 2 at x[m]
+// so a coarse tile of 2 x 4 x 32 voxels plus a ONE-voxel halo on the high side of each dimension (3 x 5 x 33 = 495 rows)
+// yields all 8 output-parity classes of its 4 x 8 x 64 fine voxels: 27 (class, tap) pairs = 27 MFMA K-steps per coarse
+// voxel and 32-channel chunk, none of them a zero-stuffed tap.  The pairs are walked by halo offset delta in {0,1}^3: the
+// voxel fragment of a delta is read once and feeds 8 / 4 / 2 / 1 pairs -- 0.8 LDS fragment reads per MFMA (the stride-1
+// kernel needs 1.5).  A wave keeps the accumulators of all 8 classes of its two 32-voxel M-tiles (256 registers), so the
+// channel chunks stream through one 109 KB LDS image (halo 39 KB + the chunk's 27 taps x 32 outputs 68 KB), one block per CU.
+// Everything else follows conv_mfma_halo2_k: persistent blocks over XCD-contiguous tile runs, buffer loads with hardware
+// zero fill, the next chunk's / tile's 22 staging pieces issued one per pair inside the MFMA loop, 80-byte LDS rows,
+// (weights x voxels) orientation with 16-byte stores, norm statistics out of the epilogue, COMA_ACCUMULATE.
+// The layer is HBM-bound at 128^3 (64 -> 32: 335 MB for 58 GFLOP): the 8 classes of a fine row pair are written from the
+// same wave back to back, so the partial 128-byte lines merge in L2.
+// =====================================================================================
+struct TconvP {
+  const void* x; int ldx; long sbx; int D, H, W, C;      // coarse input
+  void* y; int ldy; long sby; int Do, Ho, Wo, N;         // fine output (<= 2 x coarse per dimension)
+  const void* w; long wsb;                               // [b][27][N][C]
+  const float* bias; int bsb;
+  int ntx, nty, ntz, ids_total, ids_per_block;
+  unsigned xbytes, wbytes;
+  int accum;
+  double2* stats; int stats_inst;
+};
+
+// The 27 (class, tap) pairs in two balanced groups of parity classes -- A = {0, 3, 5, 6} (13 pairs), B = {1, 2, 4, 7} (14
+// pairs) -- each walked by halo offset delta.  A wave holds the accumulators of ONE group at a time (4 classes x 2 M-tiles =
+// 128 registers; all 8 classes at once spilled 135 registers next to the 22 staging pieces in flight), so a tile is two
+// passes over its channel chunks, each staging the halo and only the 13 / 14 taps it needs (75 KB of LDS).  Every tap
+// belongs to exactly one pair: LDS weight slot k of a pass holds the tap of pair k.
+__device__ constexpr int TC_NP[2] = {13, 14};
+__device__ constexpr int TC_DELTA[2][14] = {{0, 0, 0, 0, 1, 1, 2, 2, 3, 4, 4, 5, 6, 6}, {0, 0, 0, 0, 1, 1, 2, 2, 3, 4, 4, 5, 6, 7}};
+__device__ constexpr int TC_LCLS[2][14] = {{0, 1, 2, 3, 1, 2, 1, 3, 1, 2, 3, 2, 3, 3}, {0, 1, 2, 3, 0, 3, 1, 3, 3, 2, 3, 3, 3, 3}};
+__device__ constexpr int TC_TAP[2][14] = {{13, 17, 23, 25, 15, 21, 11, 19, 9, 5, 7, 3, 1, 27}, {14, 16, 22, 26, 12, 24, 10, 20, 18, 4, 8, 6, 2, 0}};
+__device__ constexpr int TC_CLS[2][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}};
+
+// STATS: the fused norm statistics (forward of the up-convolutions); without them the kernel also takes COMA_ACCUMULATE
+// (data gradients).  Two instantiations because the statistics' 32 accumulators are live across the whole tile loop: the
+// variant without them needs no scratch.
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
+  constexpr int EPB = elem<T>::EPB;
+  constexpr bool F32 = EPB == 4;
+  constexpr int CK = 4 * EPB;                          // channels per 64-byte LDS row: 32 bf16 / 16 fp32
+  constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 1, HY = TY + 1, HZ = TZ + 1, HV = HX * HY * HZ;   // 495 halo rows
+  constexpr int P = 80;                                // LDS row pitch (bytes): conflict-free ds_read_b128 over 16 consecutive rows
+  constexpr int HP = HV * 4, HIT = (HP + 255) / 256;   // 1980 halo pieces of 16 bytes -> 8 per thread
+  constexpr int WS = 14, WP = WS * 32 * 4, WIT = WP / 256;   // 14 weight slots = 1792 pieces -> 7 per thread
+  static_assert(WP % 256 == 0 && HIT + WIT <= 2 * 13, "at most two prefetch pieces per (class, tap) pair");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Hl = smem;                                     // [HV][80]
+  char* Wl = smem + HV * P;                            // [14 * 32][80]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.z, n0 = blockIdx.y * 32;
+  const int fr = lane & 31, fh = lane >> 5;
+  const T* xb = static_cast<const T*>(p.x) + (long)b * p.sbx;
+  const T* wb = static_cast<const T*>(p.w) + (long)b * p.wsb;
+  T* yb = static_cast<T*>(p.y) + (long)b * p.sby;
+  const int nchunks = p.C / CK;
+
+  // ---- staging descriptors (tile independent).  Halo piece: element offset in x relative to the tile origin, and
+  // LDS byte offset | hz << 20 | hy << 23 | hx << 26 packed into one register ----
+  int h_roff[HIT];
+  unsigned h_pack[HIT];
+#pragma unroll
+  for (int it = 0; it < HIT; ++it) {
+    const int piece = tid + 256 * it;
+    const int row = piece >> 2, ch = piece & 3;
+    const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+    h_roff[it] = ((hz * p.H + hy) * p.W + hx) * p.ldx + ch * EPB;
+    h_pack[it] = (unsigned)(row * P + ch * 16) | ((unsigned)(piece < HP ? hz : 7) << 20) | ((unsigned)hy << 23) | ((unsigned)hx << 26);
+  }
+  // weight piece `it` of this thread: slot 2 it + (tid >> 7), output row n = (tid >> 2) & 31, 16-byte chunk tid & 3
+  const int w_s0 = tid >> 7, w_n = (tid >> 2) & 31, w_ch = tid & 3;
+  const unsigned w_row = (unsigned)(((long)(n0 + w_n) * p.C + w_ch * EPB) * (long)sizeof(T));
+  const unsigned w_tap = (unsigned)((long)p.N * p.C * (long)sizeof(T));         // bytes between two taps
+  const int w_lds0 = (w_s0 * 32 + w_n) * P + w_ch * 16;
+  constexpr int W_LSTEP = 2 * 32 * P;
+  constexpr unsigned OOB = 0x7fff0000u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wb), 0, p.wbytes, 0x00020000);
+
+  // fragment read bases: voxel operand = this lane's coarse voxel row in each of the wave's two M-tiles
+  int a_base[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = wid * 2 + i;
+    a_base[i] = (((j >> 2) * HY + (j & 3)) * HX + fr) * P + fh * 16;
+  }
+  const int w_base = fr * P + fh * 16;
+
+  uint4 hreg[HIT], wreg[WIT];
+  auto halo_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int it, int z0, int y0, int x0, unsigned org_b) -> uint4 {
+    const unsigned pk = h_pack[it];
+    const bool ok = z0 + (int)((pk >> 20) & 7) < p.D && y0 + (int)((pk >> 23) & 7) < p.H && x0 + (int)(pk >> 26) < p.W;
+    const unsigned voff = ok ? org_b + (unsigned)h_roff[it] * (unsigned)sizeof(T) : OOB;
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  // slot 2 it + w_s0 of pass `grp` holds tap TC_TAP[grp][slot] (27 = the empty 14th slot of group A: reads as zero)
+  auto w_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int it, int grp, int c0_b) -> uint4 {
+    const int ta = w_s0 ? TC_TAP[0][2 * it + 1] : TC_TAP[0][2 * it], tb = w_s0 ? TC_TAP[1][2 * it + 1] : TC_TAP[1][2 * it];
+    const int tap = grp ? tb : ta;
+    const unsigned voff = tap < 27 ? w_row + (unsigned)tap * w_tap : OOB;
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, c0_b, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  auto tile_org = [&](int z0, int y0, int x0, int c0) -> unsigned {
+    return (unsigned)((((long)(z0 * p.H + y0) * p.W + x0) * p.ldx + c0) * (long)sizeof(T));
+  };
+
+  const int id_begin = xcd_remap(blockIdx.x, gridDim.x) * p.ids_per_block;
+  int id_end = id_begin + p.ids_per_block;
+  if (id_end > p.ids_total) id_end = p.ids_total;
+  int id = id_begin, tix = 0, tiy = 0, tiz = 0;
+  while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
+  if (id >= id_end) return;
+  {
+    const unsigned org = tile_org(tiz * TZ, tiy * TY, tix * TX, 0);
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) hreg[it] = halo_piece(rs_x, it, tiz * TZ, tiy * TY, tix * TX, org);
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) wreg[it] = w_piece(rs_w, it, 0, 0);
+  }
+
+  constexpr bool do_stats = STATS;
+  const bool accum = !STATS && p.accum;
+  float st_s[4][4], st_q[4][4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { st_s[g4][q] = 0.f; st_q[g4][q] = 0.f; }
+
+  while (id < id_end) {
+    const int x0 = tix * TX, y0 = tiy * TY, z0 = tiz * TZ;
+    int nid = id + 1, ntix = 0, ntiy = 0, ntiz = 0;
+    while (nid < id_end && !tile_coords(nid, p.ntx, p.nty, p.ntz, ntix, ntiy, ntiz)) ++nid;
+    const bool has_next = nid < id_end;
+
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+      f32x16_t acc[4][2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[c][i][e] = 0.f;
+
+      for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();                       // all waves finished reading the previous halo / weights
+#pragma unroll
+        for (int it = 0; it < HIT; ++it)
+          if (tid + 256 * it < HP) *reinterpret_cast<uint4*>(Hl + (h_pack[it] & 0xfffffu)) = hreg[it];
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) *reinterpret_cast<uint4*>(Wl + w_lds0 + it * W_LSTEP) = wreg[it];
+        __syncthreads();
+        // what to prefetch while this step computes: the next chunk of this pass, chunk 0 of the tile's second pass, or
+        // chunk 0 / pass A of the next tile; through descriptors whose range is zero when there is nothing left (no branch)
+        const bool same_pass = cc + 1 < nchunks;
+        const bool same_tile = same_pass || grp == 0;
+        const bool pref = same_tile || has_next;
+        const int pz = same_tile ? z0 : ntiz * TZ, py = same_tile ? y0 : ntiy * TY, px = same_tile ? x0 : ntix * TX;
+        const int pc0 = same_pass ? (cc + 1) * CK : 0;
+        const int pgrp = same_pass ? grp : 1 - grp;
+        const __amdgpu_buffer_rsrc_t rs_xp = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, pref ? p.xbytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wb), 0, pref ? p.wbytes : 0, 0x00020000);
+        const unsigned porg = tile_org(pz, py, px, pc0);
+        const int pc0_b = pc0 * (int)sizeof(T);
+
+        uint4 wv[2][2], xv[2][2][2];           // fragments one pair (weights) / one delta (voxels) ahead
+        auto rd_w = [&](int k, int bf) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) wv[bf][ks] = *reinterpret_cast<const uint4*>(Wl + w_base + k * 32 * P + ks * 32);
+        };
+        auto rd_x = [&](int di, int bf) {
+          const int doff = ((((di >> 2) & 1) * HY + ((di >> 1) & 1)) * HX + (di & 1)) * P;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xv[bf][i][ks] = *reinterpret_cast<const uint4*>(Hl + a_base[i] + doff + ks * 32);
+        };
+        rd_x(0, 0);
+        rd_w(0, 0);
+        constexpr int NPMAX = 14;
+#pragma unroll
+        for (int k = 0; k < NPMAX; ++k) {
+          if (k >= TC_NP[grp]) continue;         // (compile time: grp and k are unrolled)
+          const int di = TC_DELTA[grp][k], lc = TC_LCLS[grp][k];
+          if (k + 1 < TC_NP[grp]) {
+            rd_w(k + 1, (k + 1) & 1);
+            if (TC_DELTA[grp][k + 1] != di) rd_x(TC_DELTA[grp][k + 1], TC_DELTA[grp][k + 1] & 1);
+          }
+          // prefetch pieces: 15 per step over 13 / 14 pairs (one per pair, the last ones two)
+          if (k < WIT) wreg[k] = w_piece(rs_wp, k, pgrp, pc0_b);
+          else if (k - WIT < HIT) hreg[k - WIT] = halo_piece(rs_xp, k - WIT, pz, py, px, porg);
+          if (k == TC_NP[grp] - 1) {
+#pragma unroll
+            for (int r = TC_NP[grp] - WIT; r < HIT; ++r) hreg[r] = halo_piece(rs_xp, r, pz, py, px, porg);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[lc][i] = mma_piece(wv[k & 1][ks], xv[di & 1][i][ks], acc[lc][i], T());
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // ---- epilogue of this pass's 4 classes: lane = one coarse voxel of each M-tile, 4 groups of 4 consecutive channels ----
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int j = wid * 2 + i;
+        const int cz = z0 + (j >> 2), cy = y0 + (j & 3), cx = x0 + fr;
+        const bool cin = cz < p.D && cy < p.H && cx < p.W;
+#pragma unroll
+        for (int lc = 0; lc < 4; ++lc) {
+          __builtin_amdgcn_sched_barrier(0);     // one class at a time: interleaved, the 8 unrolled instances spill
+          const int cls = TC_CLS[grp][lc];
+          const int gz = 2 * cz + (cls >> 2), gy = 2 * cy + ((cls >> 1) & 1), gx = 2 * cx + (cls & 1);
+          const bool valid = cin && gz < p.Do && gy < p.Ho && gx < p.Wo;
+          const long voff = ((long)(gz * p.Ho + gy) * p.Wo + gx) * p.ldy + n0;
+          float of[4][4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              of[g4][q] = acc[lc][i][g4 * 4 + q] + (p.bias ? p.bias[b * p.bsb + n0 + 8 * g4 + 4 * fh + q] : 0.f);
+          if constexpr (F32) {
+            float* dst = reinterpret_cast<float*>(yb) + voff + 4 * fh;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (accum && valid) old = *reinterpret_cast<const float4*>(dst + 8 * g4);
+              const float o[4] = {of[g4][0] + old.x, of[g4][1] + old.y, of[g4][2] + old.z, of[g4][3] + old.w};
+              if (do_stats) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float r = valid ? o[q] : 0.f; st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]); }
+              }
+              if (valid) *reinterpret_cast<float4*>(dst + 8 * g4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+          } else {
+            // the two half-waves exchange 4-channel groups (v_permlane32_swap): every lane then owns 8 CONSECUTIVE channels
+            // of its voxel per 16-channel half and writes them with one 16-byte store (as conv_mfma_halo2_k)
+            bf16_t* vox = reinterpret_cast<bf16_t*>(yb) + voff + 8 * fh;
+            if (accum) {
+              // y += : what is already there, brought into the accumulators' lane layout -- a lane reads the 8 consecutive
+              // channels it will store (fh = 0: 16 gp + 0..7, fh = 1: 16 gp + 8..15) and the halves swap back the 4-channel
+              // groups that belong to the other one (the inverse of the exchange in front of the store)
+#pragma unroll
+              for (int gp = 0; gp < 2; ++gp) {
+                uint4 u = make_uint4(0, 0, 0, 0);
+                if (valid) u = *reinterpret_cast<const uint4*>(vox + 16 * gp);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(u.x, u.z, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(u.y, u.w, false, false);
+                const unsigned w0[2] = {s0[0], s1[0]}, w1[2] = {s0[1], s1[1]};       // channel group 2 gp / 2 gp + 1 of this lane
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  of[2 * gp][2 * h] += __uint_as_float(w0[h] << 16); of[2 * gp][2 * h + 1] += __uint_as_float(w0[h] & 0xffff0000u);
+                  of[2 * gp + 1][2 * h] += __uint_as_float(w1[h] << 16); of[2 * gp + 1][2 * h + 1] += __uint_as_float(w1[h] & 0xffff0000u);
+                }
+              }
+            }
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              bf16_t o[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                o[q] = static_cast<bf16_t>(of[g4][q]);
+                if (do_stats) { const float r = valid ? static_cast<float>(o[q]) : 0.f; st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]); }
+              }
+              const uint2 u = *reinterpret_cast<const uint2*>(o);
+              pk[g4][0] = u.x; pk[g4][1] = u.y;
+            }
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
+              const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
+              if (valid) *reinterpret_cast<uint4*>(vox + 16 * gp) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            }
+          }
+        }
+      }
+    }
+    id = nid; tix = ntix; tiy = ntiy; tiz = ntiz;
+  }
+  // ---- fused statistics (as conv_mfma_halo2_k) ----
+  if (STATS) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = st_s[g4][q], c = st_q[g4][q];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+        if (fr == 0) { red[(wid * 32 + 8 * g4 + 4 * fh + q) * 2] = a; red[(wid * 32 + 8 * g4 + 4 * fh + q) * 2 + 1] = c; }
+      }
+    __syncthreads();
+    if (tid < 32 && n0 + tid < p.N) {
+      double a = 0.0, c = 0.0;
+      for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
+      const int g = p.stats_inst ? b : 0;
+      stat_add(p.stats, p.stats_inst ? p.stats_inst : 1, p.N, g, n0 + tid, a, c);
+    }
+  }
+}
+
+static bool tconv_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  if (d->form != 1 || d->stride != 2 || d->ksize != 3 || x->dtype != y->dtype) return false;
+  static const bool off = getenv("COMA_NO_TCONV") != nullptr;      // (A/B measurements against the gather kernel)
+  if (off) return false;
+  const int es = esize(x->dtype), ck = 64 / es;
+  if (x->W < 32 || x->C % ck || y->C % 32) return false;
+  if ((x->ld * es) % 16 || (x->sb * es) % 16 || (y->ld * es) % 16 || (y->sb * es) % 16) return false;
+  if ((x->data && !aligned16(x->data)) || (y->data && !aligned16(y->data))) return false;
+  if (y->D > 2 * x->D || y->H > 2 * x->H || y->W > 2 * x->W || y->D < 2 * x->D - 1 || y->H < 2 * x->H - 1 || y->W < 2 * x->W - 1) return false;
+  return (unsigned long long)t_vox(x) * x->ld * es < 0x7fff0000ull && (long)t_vox(y) * y->ld < (1L << 31);
+}
+
+template <typename T>
+static int conv_mfma_tconv(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias, const coma_tensor* y,
+                           hipStream_t s, double2* stats, int stats_inst, int* stats_chunks, int accum) {
+  COMA_CHECK(aligned16(wk), "conv_mfma_tconv: weights must be 16-byte aligned");
+  TconvP q;
+  q.x = x->data; q.ldx = (int)x->ld; q.sbx = x->sb; q.D = x->D; q.H = x->H; q.W = x->W; q.C = x->C;
+  q.y = y->data; q.ldy = (int)y->ld; q.sby = y->sb; q.Do = y->D; q.Ho = y->H; q.Wo = y->W; q.N = y->C;
+  q.w = wk; q.wsb = d->per_sample_w ? 27L * y->C * x->C : 0;
+  q.bias = bias; q.bsb = d->per_sample_w ? y->C : 0;
+  q.xbytes = (unsigned)((unsigned long long)t_vox(x) * x->ld * sizeof(T));
+  q.wbytes = (unsigned)(27ull * y->C * x->C * sizeof(T));
+  q.accum = accum;
+  q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
+  q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
+  const int nblk_n = y->C / 32;
+  int gx = 512 / (nblk_n * x->B);                      // one block per CU, about two rounds
+  if (gx < 1) gx = 1;
+  if (gx > q.ids_total) gx = q.ids_total;
+  q.ids_per_block = (q.ids_total + gx - 1) / gx;
+  gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
+  q.stats = nullptr; q.stats_inst = stats_inst;
+  static const bool fuse_stats = getenv("COMA_TCONV_NO_STATS") == nullptr;      // (A/B: statistics as a separate pass)
+  if (stats && !accum && fuse_stats) { q.stats = stats; *stats_chunks = 1; }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_mfma_tconv_k<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_tconv_k<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_tconv_k<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_tconv_k<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const size_t lds = (size_t)(33 * 5 * 3 + 14 * 32) * 80;
+  coma_set_kernel_tag("conv_mfma_tconv_k<%s, %d>", sizeof(T) == 2 ? "__bf16" : "float", q.stats ? 1 : 0);
+  const dim3 grid((unsigned)gx, (unsigned)nblk_n, (unsigned)x->B);
+  if (q.stats) hipLaunchKernelGGL((conv_mfma_tconv_k<T, true>), grid, dim3(256), lds, s, q);
+  else hipLaunchKernelGGL((conv_mfma_tconv_k<T, false>), grid, dim3(256), lds, s, q);
+  COMA_LAUNCH_CHECK();
+  return 0;
+}
+
 bool conv_mfma_supported(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (x->dtype != COMA_BF16 || y->dtype != COMA_BF16) return false;
   if ((long)t_vox(x) * x->ld >= (1L << 31) || (long)t_vox(y) * y->ld >= (1L << 31)) return false;
@@ -1900,6 +2267,7 @@ static int gather_ksplit(long blocks, int nsteps, bool f32);
 size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (x->dtype == COMA_F32) { if (thin16f_ok(d, x, y) || f32_halo_ok(d, x, y)) return 0; }
   else if (halo_ok(d, x, y) || pw_ok(d, x, y)) return 0;
+  if (tconv_ok(d, x, y)) return 0;
   const size_t bytes = sizeof(float) * (size_t)y->B * t_vox(y) * y->C;
   if (bytes > ((size_t)64 << 20)) return 0;
   // only when launch_gather will really split the K loop (the same arithmetic as there): callers that hand out private
@@ -1921,6 +2289,10 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
   if (f32 && thin16f_ok(d, x, y)) return conv_thin16f(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
   if (f32) { if (f32_halo_ok(d, x, y)) return conv_mfma_halo<float>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks); }
   else if (halo_ok(d, x, y)) return conv_mfma_halo<bf16_t>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
+  if (tconv_ok(d, x, y)) {
+    if (f32) return conv_mfma_tconv<float>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks, accum);
+    return conv_mfma_tconv<bf16_t>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks, accum);
+  }
   if (!f32 && pw_ok(d, x, y) && !(x->C % 32 == 0 && y->C % 32 == 0 && x->C * y->C > 64 * 32)) {
     COMA_CHECK(aligned16(wk), "conv_mfma: weights must be 16-byte aligned");
     PwP q;

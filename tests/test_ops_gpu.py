@@ -861,3 +861,97 @@ def test_grad_fork_accumulates_in_kernel_epilogues(dtype):
     torch.autograd.backward(outs, [to_int(t).to("cuda", dtype) for t in gys])
     assert rel(to_ext(xi.grad), xr.grad) < 3 * TOL[dtype], rel(to_ext(xi.grad), xr.grad)
     assert xf._coma_fork.buf is None          # the meeting point was handed back
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dims", [(3, 5, 34), (2, 4, 64), (5, 3, 32)])
+def test_tconv_halo_kernel_stats_and_accumulate(dims, dtype):
+    """conv_mfma_tconv_k (round 3: the stride-2 transposed convolution / stride-2 data gradient with the coarse halo in
+    LDS, 8 output-parity classes from 27 (class, tap) pairs): forward with per-sample weights and bias against fp64
+    F.conv_transpose3d, the fused InstanceNorm statistics against the stored output, and COMA_ACCUMULATE (y += conv(x):
+    a data gradient added into a buffer another consumer has already written) -- with the kernel that ran asserted."""
+    ops, L = _ops()
+    lib = L.lib
+    cin, cout, B, E = 64, 32, 2, 3
+    g = torch.Generator().manual_seed(sum(dims))
+    q = (lambda t: t.bfloat16().double()) if dtype == torch.bfloat16 else (lambda t: t.double())
+    x = q(torch.randn((B, cin, *dims), generator=g))
+    master = torch.randn((E, cin, cout, 3, 3, 3), generator=g) * 0.1
+    r = torch.rand((B, E), generator=g)
+    wmix = torch.einsum("be,e...->b...", r.double(), master.double())
+    if dtype == torch.bfloat16:
+        wmix = wmix.float().bfloat16().double()
+    bias = torch.randn((B, cout), generator=g)
+    yr = torch.cat([F.conv_transpose3d(x[i:i + 1], wmix[i], bias[i].double(), stride=2, padding=1, output_padding=1) for i in range(B)], 0)
+    xi = to_int(x).to("cuda", dtype)
+    wk_f, _ = ops.PrepWeights.apply(master.cuda(), r.cuda(), True, dtype, None)
+    algo = 2 if dtype == torch.bfloat16 else 0
+    y, sums = ops._conv_fwd(xi, wk_f, bias.cuda(), 3, 2, 1, True, algo, None, L.NORM_INSTANCE)
+    tag = lib.coma_last_kernel().decode()
+    assert tag.startswith("conv_mfma_tconv_k<%s" % ("__bf16" if dtype == torch.bfloat16 else "float")), tag
+    tol = 5e-3 if dtype == torch.bfloat16 else 2e-5
+    assert torch.isfinite(y.float()).all() and rel(to_ext(y), yr) < tol, rel(to_ext(y), yr)
+    mean, rstd = ops.stats_from_sums(sums, B, cout, y.shape[1] * y.shape[2] * y.shape[3], 1e-5)
+    yf = y.double()
+    m_ref, v_ref = yf.mean((1, 2, 3)), yf.var((1, 2, 3), unbiased=False)
+    assert float((mean.double() - m_ref).abs().max()) < 1e-5 * (1.0 + float(m_ref.abs().max()))
+    assert rel(rstd.double(), (v_ref + 1e-5).rsqrt()) < 1e-5
+    # y2 += conv(x) (no bias): the accumulate epilogue
+    base = q(torch.randn(yr.shape, generator=g))
+    y2 = to_int(base).to("cuda", dtype).contiguous()
+    d = ops._desc(3, 2, 1, True, algo)
+    cx, cy = L.ct(xi), L.ct(y2)
+    assert lib.coma_conv_accumulate_ok(d, cx, cy) == 1
+    ws = L.workspace(lib.coma_conv_fwd_ws_bytes(d, cx, cy), xi.device)
+    L.check(lib.coma_conv_fwd_ws(d, cx, L.ptr(wk_f), L.dtype_code(wk_f.dtype), None, cy, L.ptr(ws), ws.numel(), L.ACCUMULATE, L.stream()),
+            "coma_conv_fwd_ws(accumulate)")
+    tag = lib.coma_last_kernel().decode()
+    assert tag.startswith("conv_mfma_tconv_k<") and tag.endswith(", 0>"), tag
+    want = base + torch.cat([F.conv_transpose3d(x[i:i + 1], wmix[i], None, stride=2, padding=1, output_padding=1) for i in range(B)], 0)
+    assert rel(to_ext(y2), want) < 2 * tol, rel(to_ext(y2), want)
+
+
+DISPATCH_ROWS = [
+    # cin, cout, k, stride, transposed, coarse/in dims, dtype -> kernel that must run forward / data gradient / weight gradient
+    (32, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_halo2_k<1, 32", "conv_mfma_halo2_k<1, 32", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
+    (64, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_halo2_k<2, 32", "conv_mfma_halo2_k<2, 32", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
+    (64, 32, 3, 2, True, (3, 4, 33), torch.bfloat16, "conv_mfma_tconv_k<__bf16", "conv_mfma_gather_k<64, 0, __bf16>", "conv_bf16_wgrad16_k<2, 1>"),
+    (32, 64, 3, 2, False, (6, 8, 66), torch.bfloat16, "conv_mfma_gather_k<64, 0, __bf16>", "conv_mfma_tconv_k<__bf16, 0>", "conv_bf16_wgrad16_k<2, 0>"),
+    (64, 32, 3, 2, True, (3, 4, 33), torch.float32, "conv_mfma_tconv_k<float", "conv_mfma_gather_k<64, 0, float>", "conv_f32_wgrad16_k<2, 1>"),
+    (32, 64, 3, 2, False, (6, 8, 66), torch.float32, "conv_mfma_gather_k<64, 0, float>", "conv_mfma_tconv_k<float, 0>", "conv_f32_wgrad16_k<2, 0>"),
+    (16, 16, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_thin16_k<16, 1>", "conv_thin16_k<16, 1>", "conv_thin16_wgrad_k<16, 1>"),
+    (32, 16, 1, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_pw_k<2, 1>", "conv_mfma_pw_k<1, 1>", "conv_mfma_wgrad2_k<1, 2, 1, 1>"),
+    (32, 32, 3, 1, False, (4, 8, 32), torch.float32, "conv_mfma_halo2_k<2, 16, 1, 1, float>", "conv_mfma_halo2_k<2, 16, 1, 1, float>", "conv_f32_wgrad16_k<1, 0>"),
+    (128, 64, 3, 2, True, (4, 4, 16), torch.bfloat16, "conv_mfma_gather_k<64, 1, __bf16>", "conv_mfma_gather_k<128, 0, __bf16>", None),
+]
+
+
+@pytest.mark.parametrize("row", DISPATCH_ROWS)
+def test_kernel_dispatch_is_what_the_tables_say(row):
+    """Which kernel a layer shape runs is a property of the library's dispatch (and of six environment switches): a
+    regression there would silently test -- and time -- an older kernel.  Every row names the variant that must run."""
+    ops, L = _ops()
+    lib = L.lib
+    cin, cout, k, s, tr, dims, dtype, want_f, want_d, want_w = row
+    B = 2
+    g = torch.Generator().manual_seed(cin + cout)
+    xi = torch.randn((B, *dims, cin), generator=g).to("cuda", dtype)
+    wshape = (cin, cout, k, k, k) if tr else (cout, cin, k, k, k)
+    master = (torch.randn(wshape, generator=g) * 0.1).cuda()
+    algo = 0
+    a_f, a_d = ops.pick_algo(xi.shape, dtype, cout, k, s, tr, False, xi.device, algo)
+    wdt = lambda a: torch.bfloat16 if a == 2 else torch.float32
+    wk_f, wk_d = ops.PrepWeights.apply(master, None, tr, wdt(a_f), wdt(a_d))
+    form = 1 if tr else 0
+    y, _ = ops._conv_fwd(xi, wk_f, None, k, s, form, False, algo, None, None)
+    got_f = lib.coma_last_kernel().decode()
+    assert got_f.startswith(want_f), (got_f, want_f)
+    dy = torch.randn(y.shape, generator=torch.Generator(device="cuda").manual_seed(1), device="cuda").to(dtype)
+    ops._conv_bwd(xi, wk_d, dy, k, s, form, False, algo, tuple(wk_f.shape), True, False, 0, None)
+    got_d = lib.coma_last_kernel().decode()
+    assert got_d.startswith(want_d), (got_d, want_d)
+    if want_w is not None:
+        ops._conv_bwd(xi, wk_d, dy, k, s, form, False, algo, tuple(wk_f.shape), False, True, 0, None)
+        got_w = lib.coma_last_kernel().decode()
+        assert got_w.startswith(want_w) or got_w.startswith("wgrad_replica_sum_k"), (got_w, want_w)
+    torch.cuda.synchronize()
