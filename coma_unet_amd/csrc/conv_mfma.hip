@@ -1721,8 +1721,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
   constexpr int WS = 14, WP = WS * 32 * 4, WIT = WP / 256;   // 14 weight slots = 1792 pieces -> 7 per thread
   static_assert(WP % 256 == 0 && HIT + WIT <= 2 * 13, "at most two prefetch pieces per (class, tap) pair");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Hl = smem;                                     // [HV][80]
-  char* Wl = smem + HV * P;                            // [14 * 32][80]
+  char* Wl = smem;                                     // [14 * 32][80]  (first: its fragment offsets then fit the ds_read immediate)
+  char* Hl = smem + WS * 32 * P;                       // [HV][80]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.z, n0 = blockIdx.y * 32;
   const int fr = lane & 31, fh = lane >> 5;
@@ -1730,26 +1730,42 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
   const T* wb = static_cast<const T*>(p.w) + (long)b * p.wsb;
   T* yb = static_cast<T*>(p.y) + (long)b * p.sby;
   const int nchunks = p.C / CK;
+  constexpr unsigned OOB = 0x7fff0000u;
 
-  // ---- staging descriptors (tile independent).  Halo piece: element offset in x relative to the tile origin, and
-  // LDS byte offset | hz << 20 | hy << 23 | hx << 26 packed into one register ----
-  int h_roff[HIT];
-  unsigned h_pack[HIT];
+  // ---- staging descriptors (tile independent).  The layer is output-heavy (8 fine voxels per coarse one): next to 216
+  // MFMAs per tile every VALU instruction counts (first version: 13 VALU per MFMA, 26 % of the wave cycles).  Halo piece:
+  // BYTE offset in x relative to the tile origin; its halo coordinates as three 9-bit fields hz << 20 | hy << 10 | hx, so
+  // that the in-volume test of a piece is ONE subtraction against the packed per-tile limits (guard bits 9 / 19 / 29
+  // survive iff every field is within its limit); its LDS byte offset ----
+  unsigned h_boff[HIT], h_zyx[HIT];
+  int h_lds[HIT];
 #pragma unroll
   for (int it = 0; it < HIT; ++it) {
     const int piece = tid + 256 * it;
     const int row = piece >> 2, ch = piece & 3;
     const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
-    h_roff[it] = ((hz * p.H + hy) * p.W + hx) * p.ldx + ch * EPB;
-    h_pack[it] = (unsigned)(row * P + ch * 16) | ((unsigned)(piece < HP ? hz : 7) << 20) | ((unsigned)hy << 23) | ((unsigned)hx << 26);
+    h_boff[it] = (unsigned)((((hz * p.H + hy) * p.W + hx) * p.ldx + ch * EPB) * (int)sizeof(T));
+    h_zyx[it] = piece < HP ? ((unsigned)hz << 20) | ((unsigned)hy << 10) | (unsigned)hx : 0x1ff00000u;      // (invalid: beyond any limit)
+    h_lds[it] = row * P + ch * 16;
   }
-  // weight piece `it` of this thread: slot 2 it + (tid >> 7), output row n = (tid >> 2) & 31, 16-byte chunk tid & 3
+  constexpr unsigned GUARD = (1u << 29) | (1u << 19) | (1u << 9);
+  // weight piece `it` of this thread: slot 2 it + (tid >> 7), output row n = (tid >> 2) & 31, 16-byte chunk tid & 3; the
+  // slot's tap differs between the two passes: both byte offsets are kept (OOB = the empty 14th slot of pass A)
   const int w_s0 = tid >> 7, w_n = (tid >> 2) & 31, w_ch = tid & 3;
-  const unsigned w_row = (unsigned)(((long)(n0 + w_n) * p.C + w_ch * EPB) * (long)sizeof(T));
-  const unsigned w_tap = (unsigned)((long)p.N * p.C * (long)sizeof(T));         // bytes between two taps
   const int w_lds0 = (w_s0 * 32 + w_n) * P + w_ch * 16;
   constexpr int W_LSTEP = 2 * 32 * P;
-  constexpr unsigned OOB = 0x7fff0000u;
+  unsigned w_off[2][WIT];
+  {
+    const unsigned w_row = (unsigned)(((long)(n0 + w_n) * p.C + w_ch * EPB) * (long)sizeof(T));
+    const unsigned w_tap = (unsigned)((long)p.N * p.C * (long)sizeof(T));         // bytes between two taps
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+      for (int it = 0; it < WIT; ++it) {
+        const int tap = w_s0 ? TC_TAP[g2][2 * it + 1] : TC_TAP[g2][2 * it];
+        w_off[g2][it] = tap < 27 ? w_row + (unsigned)tap * w_tap : OOB;
+      }
+  }
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, p.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wb), 0, p.wbytes, 0x00020000);
 
@@ -1763,18 +1779,20 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
   const int w_base = fr * P + fh * 16;
 
   uint4 hreg[HIT], wreg[WIT];
-  auto halo_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int it, int z0, int y0, int x0, unsigned org_b) -> uint4 {
-    const unsigned pk = h_pack[it];
-    const bool ok = z0 + (int)((pk >> 20) & 7) < p.D && y0 + (int)((pk >> 23) & 7) < p.H && x0 + (int)(pk >> 26) < p.W;
-    const unsigned voff = ok ? org_b + (unsigned)h_roff[it] * (unsigned)sizeof(T) : OOB;
+  // lim: the tile's packed limits ((D - z0 - 1) << 20 | (H - y0 - 1) << 10 | (W - x0 - 1)) | GUARD, fields clamped to 511
+  auto tile_lim = [&](int z0, int y0, int x0) -> unsigned {
+    const int lz = p.D - z0 - 1 < 511 ? p.D - z0 - 1 : 511, ly = p.H - y0 - 1 < 511 ? p.H - y0 - 1 : 511, lx = p.W - x0 - 1 < 511 ? p.W - x0 - 1 : 511;
+    return ((unsigned)lz << 20) | ((unsigned)ly << 10) | (unsigned)lx | GUARD;
+  };
+  auto halo_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int it, unsigned lim, unsigned org_b) -> uint4 {
+    const bool ok = ((lim - h_zyx[it]) & GUARD) == GUARD;
+    const unsigned voff = ok ? org_b + h_boff[it] : OOB;
     const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
     return make_uint4(v[0], v[1], v[2], v[3]);
   };
   // slot 2 it + w_s0 of pass `grp` holds tap TC_TAP[grp][slot] (27 = the empty 14th slot of group A: reads as zero)
   auto w_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int it, int grp, int c0_b) -> uint4 {
-    const int ta = w_s0 ? TC_TAP[0][2 * it + 1] : TC_TAP[0][2 * it], tb = w_s0 ? TC_TAP[1][2 * it + 1] : TC_TAP[1][2 * it];
-    const int tap = grp ? tb : ta;
-    const unsigned voff = tap < 27 ? w_row + (unsigned)tap * w_tap : OOB;
+    const unsigned voff = grp ? w_off[1][it] : w_off[0][it];
     const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, c0_b, 0);
     return make_uint4(v[0], v[1], v[2], v[3]);
   };
@@ -1789,9 +1807,9 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
   while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, tix, tiy, tiz)) ++id;
   if (id >= id_end) return;
   {
-    const unsigned org = tile_org(tiz * TZ, tiy * TY, tix * TX, 0);
+    const unsigned org = tile_org(tiz * TZ, tiy * TY, tix * TX, 0), lim = tile_lim(tiz * TZ, tiy * TY, tix * TX);
 #pragma unroll
-    for (int it = 0; it < HIT; ++it) hreg[it] = halo_piece(rs_x, it, tiz * TZ, tiy * TY, tix * TX, org);
+    for (int it = 0; it < HIT; ++it) hreg[it] = halo_piece(rs_x, it, lim, org);
 #pragma unroll
     for (int it = 0; it < WIT; ++it) wreg[it] = w_piece(rs_w, it, 0, 0);
   }
@@ -1824,7 +1842,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
         __syncthreads();                       // all waves finished reading the previous halo / weights
 #pragma unroll
         for (int it = 0; it < HIT; ++it)
-          if (tid + 256 * it < HP) *reinterpret_cast<uint4*>(Hl + (h_pack[it] & 0xfffffu)) = hreg[it];
+          if (tid + 256 * it < HP) *reinterpret_cast<uint4*>(Hl + h_lds[it]) = hreg[it];
 #pragma unroll
         for (int it = 0; it < WIT; ++it) *reinterpret_cast<uint4*>(Wl + w_lds0 + it * W_LSTEP) = wreg[it];
         __syncthreads();
@@ -1838,7 +1856,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
         const int pgrp = same_pass ? grp : 1 - grp;
         const __amdgpu_buffer_rsrc_t rs_xp = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, pref ? p.xbytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wb), 0, pref ? p.wbytes : 0, 0x00020000);
-        const unsigned porg = tile_org(pz, py, px, pc0);
+        const unsigned porg = tile_org(pz, py, px, pc0), plim = tile_lim(pz, py, px);
         const int pc0_b = pc0 * (int)sizeof(T);
 
         uint4 wv[2][2], xv[2][2][2];           // fragments one pair (weights) / one delta (voxels) ahead
@@ -1866,10 +1884,10 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
           }
           // prefetch pieces: 15 per step over 13 / 14 pairs (one per pair, the last ones two)
           if (k < WIT) wreg[k] = w_piece(rs_wp, k, pgrp, pc0_b);
-          else if (k - WIT < HIT) hreg[k - WIT] = halo_piece(rs_xp, k - WIT, pz, py, px, porg);
+          else if (k - WIT < HIT) hreg[k - WIT] = halo_piece(rs_xp, k - WIT, plim, porg);
           if (k == TC_NP[grp] - 1) {
 #pragma unroll
-            for (int r = TC_NP[grp] - WIT; r < HIT; ++r) hreg[r] = halo_piece(rs_xp, r, pz, py, px, porg);
+            for (int r = TC_NP[grp] - WIT; r < HIT; ++r) hreg[r] = halo_piece(rs_xp, r, plim, porg);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1880,24 +1898,31 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
         }
       }
       // ---- epilogue of this pass's 4 classes: lane = one coarse voxel of each M-tile, 4 groups of 4 consecutive channels ----
+      const bool has_bias = p.bias != nullptr;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int j = wid * 2 + i;
         const int cz = z0 + (j >> 2), cy = y0 + (j & 3), cx = x0 + fr;
         const bool cin = cz < p.D && cy < p.H && cx < p.W;
+        const bool vz1 = 2 * cz + 1 < p.Do, vy1 = 2 * cy + 1 < p.Ho, vx1 = 2 * cx + 1 < p.Wo;      // (odd fine sizes: the last odd plane is absent)
+        const long vbase = ((long)(2 * cz * p.Ho + 2 * cy) * p.Wo + 2 * cx) * p.ldy + n0;         // fine voxel (2cz, 2cy, 2cx)
 #pragma unroll
         for (int lc = 0; lc < 4; ++lc) {
           __builtin_amdgcn_sched_barrier(0);     // one class at a time: interleaved, the 8 unrolled instances spill
           const int cls = TC_CLS[grp][lc];
-          const int gz = 2 * cz + (cls >> 2), gy = 2 * cy + ((cls >> 1) & 1), gx = 2 * cx + (cls & 1);
-          const bool valid = cin && gz < p.Do && gy < p.Ho && gx < p.Wo;
-          const long voff = ((long)(gz * p.Ho + gy) * p.Wo + gx) * p.ldy + n0;
+          const bool valid = cin && (!(cls & 4) || vz1) && (!(cls & 2) || vy1) && (!(cls & 1) || vx1);
+          const long voff = vbase + ((long)(((cls >> 2) & 1) * p.Ho + ((cls >> 1) & 1)) * p.Wo + (cls & 1)) * p.ldy;   // (scalar class offset)
           float of[4][4];
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              of[g4][q] = acc[lc][i][g4 * 4 + q] + (p.bias ? p.bias[b * p.bsb + n0 + 8 * g4 + 4 * fh + q] : 0.f);
+            for (int q = 0; q < 4; ++q) of[g4][q] = acc[lc][i][g4 * 4 + q];
+          if (has_bias) {                        // (uniform)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) of[g4][q] += p.bias[b * p.bsb + n0 + 8 * g4 + 4 * fh + q];
+          }
           if constexpr (F32) {
             float* dst = reinterpret_cast<float*>(yb) + voff + 4 * fh;
 #pragma unroll

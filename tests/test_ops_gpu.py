@@ -914,7 +914,7 @@ def test_tconv_halo_kernel_stats_and_accumulate(dims, dtype):
 DISPATCH_ROWS = [
     # cin, cout, k, stride, transposed, coarse/in dims, dtype -> kernel that must run forward / data gradient / weight gradient
     (32, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_halo2_k<1, 32", "conv_mfma_halo2_k<1, 32", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
-    (64, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_halo2_k<2, 32", "conv_mfma_halo2_k<2, 32", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
+    (64, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_halo2_k<2, 32", "conv_mfma_halo2_k<1, 32", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
     (64, 32, 3, 2, True, (3, 4, 33), torch.bfloat16, "conv_mfma_tconv_k<__bf16", "conv_mfma_gather_k<64, 0, __bf16>", "conv_bf16_wgrad16_k<2, 1>"),
     (32, 64, 3, 2, False, (6, 8, 66), torch.bfloat16, "conv_mfma_gather_k<64, 0, __bf16>", "conv_mfma_tconv_k<__bf16, 0>", "conv_bf16_wgrad16_k<2, 0>"),
     (64, 32, 3, 2, True, (3, 4, 33), torch.float32, "conv_mfma_tconv_k<float", "conv_mfma_gather_k<64, 0, float>", "conv_f32_wgrad16_k<2, 1>"),
