@@ -1676,14 +1676,20 @@ static bool pw_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_tens
 // so a coarse tile of 2 x 4 x 32 voxels plus a ONE-voxel halo on the high side of each dimension (3 x 5 x 33 = 495 rows)
 // yields all 8 output-parity classes of its 4 x 8 x 64 fine voxels: 27 (class, tap) pairs = 27 MFMA K-steps per coarse
 // voxel and 32-channel chunk, none of them a zero-stuffed tap.  The pairs are walked by halo offset delta in {0,1}^3: the
-// voxel fragment of a delta is read once and feeds 8 / 4 / 2 / 1 pairs -- 0.8 LDS fragment reads per MFMA (the stride-1
-// kernel needs 1.5).  A wave keeps the accumulators of all 8 classes of its two 32-voxel M-tiles (256 registers), so the
-// channel chunks stream through one 109 KB LDS image (halo 39 KB + the chunk's 27 taps x 32 outputs 68 KB), one block per CU.
+// voxel fragment of a delta is read once and feeds up to 8 pairs -- about one LDS fragment read per MFMA (the stride-1
+// kernel needs 1.5).  The classes are processed in two balanced passes of 4 (13 + 14 pairs; see TC_* below): a wave keeps
+// 4 classes x 2 M-tiles = 128 accumulator registers and each pass streams the channel chunks through one 75 KB LDS image
+// (the pass's 14 weight slots x 32 outputs 35 KB + halo 39 KB), one block per CU.
 // Everything else follows conv_mfma_halo2_k: persistent blocks over XCD-contiguous tile runs, buffer loads with hardware
-// zero fill, the next chunk's / tile's 22 staging pieces issued one per pair inside the MFMA loop, 80-byte LDS rows,
-// (weights x voxels) orientation with 16-byte stores, norm statistics out of the epilogue, COMA_ACCUMULATE.
-// The layer is HBM-bound at 128^3 (64 -> 32: 335 MB for 58 GFLOP): the 8 classes of a fine row pair are written from the
-// same wave back to back, so the partial 128-byte lines merge in L2.
+// zero fill, the next step's 15 staging pieces issued inside the MFMA loop, 80-byte LDS rows, (weights x voxels)
+// orientation with 16-byte stores, norm statistics out of the epilogue (STATS), COMA_ACCUMULATE.
+// Measured (MI355X, 2 x 64^3 x 64 -> 2 x 128^3 x 32, 58 GFLOP, 335 MB): 139 us = 416 TFLOP/s against 298 us on the gather
+// kernel; 128 -> 64 to 64^3: 51 us = 567 TFLOP/s against 94 us.  The layer is output-heavy (8 fine voxels per coarse one:
+// 256 outputs per lane and tile next to 216 MFMAs) and memory-side bound: PMC of the first version 262 MB written (exact)
+// but 130-260 MB fetched for 67 MB of input (the output stream evicts the halo between the two passes; TCC hit rate 61 %),
+// 41 % of the wave cycles waiting.  Two blocks per CU (a 256-register variant, 12 spilled registers) measured 147 us /
+// 47 us: no gain where it matters, so one block per CU stays.  Next: both channel chunks of a tile's halo resident for its
+// two passes (C = 64: 115 KB), or LDS-DMA staging into a double-buffered image.
 // =====================================================================================
 struct TconvP {
   const void* x; int ldx; long sbx; int D, H, W, C;      // coarse input

@@ -920,7 +920,7 @@ DISPATCH_ROWS = [
     (64, 32, 3, 2, True, (3, 4, 33), torch.float32, "conv_mfma_tconv_k<float", "conv_mfma_gather_k<64, 0, float>", "conv_f32_wgrad16_k<2, 1>"),
     (32, 64, 3, 2, False, (6, 8, 66), torch.float32, "conv_mfma_gather_k<64, 0, float>", "conv_mfma_tconv_k<float, 0>", "conv_f32_wgrad16_k<2, 0>"),
     (16, 16, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_thin16_k<16, 1>", "conv_thin16_k<16, 1>", "conv_thin16_wgrad_k<16, 1>"),
-    (32, 16, 1, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_pw_k<2, 1>", "conv_mfma_pw_k<1, 1>", "conv_mfma_wgrad2_k<1, 2, 1, 1>"),
+    (32, 16, 1, 1, False, (8, 16, 32), torch.bfloat16, "conv_mfma_pw_k<2, 1>", "conv_mfma_pw_k<1, 1>", "conv_mfma_wgrad2_k<1, 2, 1, 1>"),
     (32, 32, 3, 1, False, (4, 8, 32), torch.float32, "conv_mfma_halo2_k<2, 16, 1, 1, float>", "conv_mfma_halo2_k<2, 16, 1, 1, float>", "conv_f32_wgrad16_k<1, 0>"),
     (128, 64, 3, 2, True, (4, 4, 16), torch.bfloat16, "conv_mfma_gather_k<64, 1, __bf16>", "conv_mfma_gather_k<128, 0, __bf16>", None),
 ]
