@@ -36,18 +36,6 @@ __device__ __forceinline__ f32x16_t mma_piece(const uint4& a, const uint4& b, f3
   return acc;
 }
 
-struct GatherP {
-  const void* x; int ldx; long sbx; int Di, Hi, Wi, C;
-  void* y; int ldy; long sby; int Do, Ho, Wo, N;
-  const void* w; long wsb;          // [b][tap][N][C]
-  const float* bias; int bsb;
-  int k, stride, flip;
-  int Mz, My, Mx;                      // M-grid (MODE 0: output grid; MODE 1: coarse grid)
-  int ksplit;                          // > 1: the K loop (taps x channel chunks) is cut into ksplit slices on blockIdx.y
-  float* part; long part_sb;           //      whose fp32 partial tiles are merged atomically into part[b][voxel][N]
-  int accum;                           // y += conv(x) instead of y = conv(x) (a data gradient added to one that is already there)
-};
-
 // fused norm statistics: a block ADDS its {sum, sumsq} of one (group, channel) to the caller's zeroed fp64 record
 // rec[COMA_STAT_REPLICAS][G][N][2] (replica stride rounded up to a 64-byte line) with global_atomic_add_f64; every consumer
 // sums the replicas and derives mean / rstd itself (norm.hip, NormStat).  Replicas: float atomics execute at the memory
@@ -59,6 +47,19 @@ __device__ __forceinline__ void stat_add(double2* rec, int G, int N, int g, int 
   unsafeAtomicAdd(q, a);
   unsafeAtomicAdd(q + 1, c);
 }
+
+struct GatherP {
+  const void* x; int ldx; long sbx; int Di, Hi, Wi, C;
+  void* y; int ldy; long sby; int Do, Ho, Wo, N;
+  const void* w; long wsb;          // [b][tap][N][C]
+  const float* bias; int bsb;
+  int k, stride, flip;
+  int Mz, My, Mx;                      // M-grid (MODE 0: output grid; MODE 1: coarse grid)
+  int ksplit;                          // > 1: the K loop (taps x channel chunks) is cut into ksplit slices on blockIdx.y
+  float* part; long part_sb;           //      whose fp32 partial tiles are merged atomically into part[b][voxel][N]
+  int accum;                           // y += conv(x) instead of y = conv(x) (a data gradient added to one that is already there)
+  double2* stats; int stats_inst;      // optional fused norm statistics of the stored outputs (not with ksplit > 1), as conv_mfma_halo2_k
+};
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 2) | (chunk ^ ((row >> 2) & 3)); }  // 16-B slot index
 
@@ -236,10 +237,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
 
   // ---- epilogue: + bias, cast, store (row = voxel, lane column = channel) ----
   T* yb = static_cast<T*>(p.y) + (long)b * p.sby;
+  const bool do_stats = p.stats != nullptr;          // (host: never together with ksplit > 1)
+  float st_s[NT], st_q[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + wn * (NT * 32) + j * 32 + fr;
     const float bv = p.bias ? p.bias[b * p.bsb + n] : 0.f;
+    st_s[j] = 0.f; st_q[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -248,9 +252,34 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_gather_k(GatherP p) {
         const int off = rowoff[row];
         if (off >= 0) {
           if (p.ksplit > 1) atomicAdd(p.part + (long)b * p.part_sb + (long)(off / p.ldy) * p.N + n, acc[i][j][e]);
-          else yb[off + n] = static_cast<T>(acc[i][j][e] + bv + (p.accum ? static_cast<float>(yb[off + n]) : 0.f));
+          else {
+            const T o = static_cast<T>(acc[i][j][e] + bv + (p.accum ? static_cast<float>(yb[off + n]) : 0.f));
+            yb[off + n] = o;
+            if (do_stats) { const float r = static_cast<float>(o); st_s[j] += r; st_q[j] = fmaf(r, r, st_q[j]); }
+          }
         }
       }
+    }
+  }
+  // fused statistics: a lane holds ONE channel per N-tile; its two half-waves (fh) and the block's M-waves fold through LDS
+  if (do_stats) {
+    __syncthreads();                                  // the K loop's LDS images are dead
+    float* red = reinterpret_cast<float*>(smem);      // [4 waves][NT][32][2]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float a = st_s[j], c = st_q[j];
+      a += __shfl_xor(a, 32, 64); c += __shfl_xor(c, 32, 64);
+      if (fh == 0) { red[((wid * NT + j) * 32 + fr) * 2] = a; red[((wid * NT + j) * 32 + fr) * 2 + 1] = c; }
+    }
+    __syncthreads();
+    for (int t = tid; t < BN; t += 256) {             // channel t of the block's BN: wave column wn = t / (NT * 32)
+      const int twn = t / (NT * 32), tj = (t / 32) % NT, tfr = t & 31;
+      double a = 0.0, c = 0.0;
+      for (int w = 0; w < 4 / WAVES_N; ++w) {
+        const int wv_ = w * WAVES_N + twn;
+        a += (double)red[((wv_ * NT + tj) * 32 + tfr) * 2]; c += (double)red[((wv_ * NT + tj) * 32 + tfr) * 2 + 1];
+      }
+      stat_add(p.stats, p.stats_inst ? p.stats_inst : 1, p.N, p.stats_inst ? b : 0, n0 + t, a, c);
     }
   }
 }
@@ -2116,7 +2145,8 @@ static int gather_ksplit(long blocks, int nsteps, bool f32) {
 }
 
 template <int BN, typename T>
-static int launch_gather(const GatherP& p0, int mode, int B, hipStream_t s, void* ws, size_t ws_bytes, int ws_zeroed) {
+static int launch_gather(const GatherP& p0, int mode, int B, hipStream_t s, void* ws, size_t ws_bytes, int ws_zeroed,
+                         double2* stats, int stats_inst, int* stats_chunks) {
   GatherP p = p0;
   constexpr int BM = (BN == 128) ? 128 : 256;
   constexpr int LCK = elem<T>::EPB == 8 ? 5 : 4;
@@ -2131,6 +2161,8 @@ static int launch_gather(const GatherP& p0, int mode, int B, hipStream_t s, void
     p.part = (float*)ws; p.part_sb = Vout * p.N;
     if (!ws_zeroed && hipMemsetAsync(ws, 0, sizeof(float) * (size_t)B * Vout * p.N, s) != hipSuccess) { coma_set_error("conv split-K memset failed"); return 2; }
   } else p.ksplit = 1;
+  p.stats = nullptr; p.stats_inst = stats_inst;
+  if (stats && p.ksplit == 1 && !p.accum) { p.stats = stats; *stats_chunks = 1; }     // (split-K: the values are not final in this kernel)
   dim3 grid(gx, gy * p.ksplit, (unsigned)B);
   coma_set_kernel_tag("conv_mfma_gather_k<%d, %d, %s>", BN, mode, LCK == 4 ? "float" : "__bf16");
   if (mode == 0) hipLaunchKernelGGL((conv_mfma_gather_k<BN, 0, T>), grid, dim3(256), lds, s, p);
@@ -2363,13 +2395,13 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
     p.Mz = y->D; p.My = y->H; p.Mx = y->W;
   }
   if (f32) {
-    if (y->C % 128 == 0) return launch_gather<128, float>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
-    if (y->C % 64 == 0) return launch_gather<64, float>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
-    return launch_gather<32, float>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
+    if (y->C % 128 == 0) return launch_gather<128, float>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed, stats, stats_inst, stats_chunks);
+    if (y->C % 64 == 0) return launch_gather<64, float>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed, stats, stats_inst, stats_chunks);
+    return launch_gather<32, float>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed, stats, stats_inst, stats_chunks);
   }
-  if (y->C % 128 == 0) return launch_gather<128, bf16_t>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
-  if (y->C % 64 == 0) return launch_gather<64, bf16_t>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
-  return launch_gather<32, bf16_t>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed);
+  if (y->C % 128 == 0) return launch_gather<128, bf16_t>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed, stats, stats_inst, stats_chunks);
+  if (y->C % 64 == 0) return launch_gather<64, bf16_t>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed, stats, stats_inst, stats_chunks);
+  return launch_gather<32, bf16_t>(p, mode, x->B, s, ws, ws_bytes, ws_zeroed, stats, stats_inst, stats_chunks);
 }
 
 // =====================================================================================
@@ -3037,12 +3069,19 @@ static bool wgrad2_ok(const coma_conv_desc* d, const coma_tensor* x, const coma_
 static long wgrad_out_elems(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* dy) {
   return (long)d->ksize * d->ksize * d->ksize * dy->C * x->C * (d->per_sample_w ? x->B : 1);
 }
+// out[i] = sum over the replicas.  A few thousand outputs x 64 replicas: the serial 64-load walk per thread this replaces was
+// latency-bound (17.7 us per launch, 13 launches per step); here 8 lanes share an output (8 independent loads each) and
+// fold through a wave shuffle.
 __global__ __launch_bounds__(256) void wgrad_replica_sum_k(const float* __restrict__ rep, int nrep, long n, float* __restrict__ out) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  const long i = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int part = threadIdx.x & 7;
   float a = 0.f;
-  for (int r = 0; r < nrep; ++r) a += rep[(long)r * n + i];
-  out[i] = a;
+  if (i < n) {
+#pragma unroll 8
+    for (int r = part; r < nrep; r += 8) a += rep[(long)r * n + i];
+  }
+  a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 1, 64);
+  if (part == 0 && i < n) out[i] = a;
 }
 
 // =====================================================================================
@@ -3426,7 +3465,7 @@ static int conv_thin16_wgrad(const coma_conv_desc* d, const coma_tensor* x, cons
   else hipLaunchKernelGGL((conv_thin16_wgrad_k<8, 1>), grid, dim3(256), lds, s, q);
   COMA_LAUNCH_CHECK();
   if (replicas) {
-    hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
+    hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 31) / 32)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
     COMA_LAUNCH_CHECK();
   }
   return 0;
@@ -3876,7 +3915,7 @@ static int conv_thin16f_wgrad(const coma_conv_desc* d, const coma_tensor* x, con
   else hipLaunchKernelGGL((conv_thin16f_wgrad_k<4, 1>), grid, dim3(256), lds, s, q);
   COMA_LAUNCH_CHECK();
   if (replicas) {
-    hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
+    hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 31) / 32)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
     COMA_LAUNCH_CHECK();
   }
   return 0;
@@ -3936,7 +3975,7 @@ static int conv_mfma_wgrad2(const coma_conv_desc* d, const coma_tensor* x, const
 #undef WG2
   COMA_LAUNCH_CHECK();
   if (replicas) {
-    hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
+    hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 31) / 32)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
     COMA_LAUNCH_CHECK();
   }
   return 0;
@@ -4074,7 +4113,7 @@ int conv_mfma_wgrad(const coma_conv_desc* d, const coma_tensor* x, const coma_te
 #undef F32WL
     COMA_LAUNCH_CHECK();
     if (replicas) {
-      hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
+      hipLaunchKernelGGL(wgrad_replica_sum_k, dim3((unsigned)((wsz + 31) / 32)), dim3(256), 0, s, (const float*)ws, WGRAD_NREP, wsz, dwk);
       COMA_LAUNCH_CHECK();
     }
     return 0;

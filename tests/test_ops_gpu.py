@@ -955,3 +955,29 @@ def test_kernel_dispatch_is_what_the_tables_say(row):
         got_w = lib.coma_last_kernel().decode()
         assert got_w.startswith(want_w) or got_w.startswith("wgrad_replica_sum_k"), (got_w, want_w)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("mode", ["instance", "batch"])
+@pytest.mark.parametrize("case", [(32, 64, 2, (6, 8, 66)), (64, 128, 2, (8, 8, 16)), (128, 128, 1, (4, 4, 8))])
+def test_gather_kernel_fused_stats(case, mode, dtype):
+    """conv_mfma_gather_k (strided and small-grid layers) with the norm statistics out of its epilogue: the record must
+    describe the STORED output (split-K launches fall back to the separate statistics pass: same record either way)."""
+    ops, L = _ops()
+    cin, cout, s, dims = case
+    B = 2
+    g = torch.Generator().manual_seed(cin + sum(dims))
+    xi = torch.randn((B, *dims, cin), generator=g).to("cuda", dtype)
+    master = (torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.05).cuda()
+    algo = 2 if dtype == torch.bfloat16 else 0
+    wk_f, _ = ops.PrepWeights.apply(master, None, False, dtype, None)
+    bias = torch.randn((cout,), generator=g).cuda()
+    y, sums = ops._conv_fwd(xi, wk_f, bias, 3, s, 0, False, algo, None, L.NORM_INSTANCE if mode == "instance" else L.NORM_BATCH)
+    G = B if mode == "instance" else 1
+    mean, rstd = ops.stats_from_sums(sums, G, cout, y.shape[1] * y.shape[2] * y.shape[3] * (1 if mode == "instance" else B), 1e-5)
+    yf = y.double()
+    red = (1, 2, 3) if mode == "instance" else (0, 1, 2, 3)
+    m_ref = yf.mean(red).reshape(mean.shape)
+    v_ref = yf.var(red, unbiased=False).reshape(mean.shape)
+    assert float((mean.double() - m_ref).abs().max()) < 1e-5 * (1.0 + float(m_ref.abs().max()))
+    assert rel(rstd.double(), (v_ref + 1e-5).rsqrt()) < 1e-5
