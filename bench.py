@@ -7,11 +7,17 @@
 One step = forward + GenerativeContrastiveLoss + backward + gradient all-reduce (N > 1) + fused
 AdamW on one batch of seeded synthetic volumes already resident in HBM.
 Rank 0 prints ONE JSON line.
- * `roofline`: the dominant convolution KERNEL (by name, as rocprofv3 prints it -- the library reports the variant each
-   dispatch launched, coma_last_kernel): achieved = summed algorithmic FLOPs (or bytes) of its launches / summed launch
-   durations, measured live with HIP events on the launching stream; `step` carries the step-level figure (U-Net FLOPs x
-   volumes / step time / peak).  `traffic` = HBM bytes per launch from the committed PMC pass of the same kernel
-   (profiles/r02_pmc_traffic.json; FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes), null if absent.
+ * `roofline`: the dominant KERNEL of the step by summed time (by name, as rocprofv3 prints it -- the library reports the
+   variant each dispatch launched, coma_last_kernel; normalisation launches are bracketed too): achieved = summed
+   algorithmic FLOPs (MFMA-bound) or bytes (HBM-bound) of its launches / summed launch durations, measured live with HIP
+   events on the launching stream; `step` carries the step-level figure (U-Net FLOPs x volumes / step time / peak).
+   `roofline_mfma` / `roofline_hbm`: the top kernel of EACH regime, so the line always names the dominant convolution and
+   the dominant bandwidth kernel.  `traffic` = HBM bytes per launch from the committed PMC passes of the same build
+   (profiles/r03_pmc_traffic.json; FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes), null if absent.
+ * `secondary` (N = 1): the eager `train_step` (what a caller without graph capture gets), the step WITH host->device
+   input staging (train.InputStager: pinned host batch -> side-stream copy -> replay), the fp32 mode at 128^3 (the
+   reference's own arithmetic: the mode that meets north_star's 1e-3) with its roofline, and BASELINE config C5
+   (192x224x192, fp32, batch 1) -- a few seconds each.
  * `cpu_baseline`: the CPU oracle (this repo's restatement of the reference path -- the reference itself cannot be
    imported) timed on the host cores: 1 warm-up + median of 3 fwd+bwd steps, rank 0, N = 1 only.
  * `parity`: rel-L2 and voxel MAE of THIS run's model (same weights, same inputs) against that oracle's forward.
@@ -76,9 +82,9 @@ def cpu_baseline(size, threads, batch=2, gpu_model_factory=None):
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json,
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes (profiles/r03_pmc_traffic.json,
     written by profiles/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     try:
@@ -87,6 +93,118 @@ def pmc_traffic(kernel_name):
         return None
     ent = tab.get(kernel_name)
     return ent if ent is None else float(ent["hbm_bytes_per_launch"])
+
+def rooflines(byk, timer_steps, peak_tf, step_roof, timer_note):
+    """(roofline, roofline_mfma, roofline_hbm) from KernelTimer.by_kernel(): per kernel name (launches, ms, flops, bytes)."""
+    def entry(kname, n, ms, fl, by, bound):
+        common = {"kernel": kname, "launches_per_step": n / timer_steps, "avg_launch_us": round(ms / n * 1e3, 2),
+                  "ms_per_step": round(ms / timer_steps, 3), "alg_flops_per_launch": round(fl / n),
+                  "alg_bytes_per_launch": round(by / n), "traffic": pmc_traffic(kname)}
+        if bound == "hbm":
+            ach = by / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBPS, 4), **common}
+        ach = fl / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), **common}
+
+    def bound_of(fl, by):      # below the MFMA/HBM ridge (~300 FLOP/B) by 2x: a bandwidth kernel
+        return "hbm" if fl / max(by, 1.0) < 150.0 else "mfma"
+    top = sorted(byk.items(), key=lambda kv: -kv[1][1])
+    if not top:
+        return None, None, None
+    ents = [(k, v, bound_of(v[2], v[3])) for k, v in top]
+    first = lambda b: next((entry(k, *v, b) for k, v, bb in ents if bb == b), None)
+    k0, v0, b0 = ents[0]
+    roof = entry(k0, *v0, b0)
+    roof.update({"step": step_roof, "measured": timer_note,
+                 "top_kernels": [{"kernel": k, "bound": bb, "launches_per_step": v[0] / timer_steps, "ms_per_step": round(v[1] / timer_steps, 3),
+                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1), "alg_GBps": round(v[3] / (v[1] * 1e-3) / 1e9)}
+                                 for k, v, bb in ents[:10]]})
+    return roof, first("mfma"), first("hbm")
+
+
+def timed_steps(fn, steps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def secondary_figures(args, dev, headline_ms, eager_ctx):
+    """Driver-visible numbers beside the headline (N = 1 only; a few seconds each) -- see the module docstring."""
+    import coma_unet_amd as cu
+    from coma_unet_amd import ops
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, make_optimizer, GraphedTrainStep, InputStager
+    out = {}
+    model, crit, opt, batch, step_fn = eager_ctx
+    # (1) the eager step of the benched model (what train_dp runs before it has captured, and any caller without capture)
+    ops.KernelTimer.enabled = False
+    for _ in range(2):
+        train_step(model, crit, opt, batch, None)
+    out["eager_train_step"] = {"ms_per_step": round(timed_steps(lambda: train_step(model, crit, opt, batch, None), 5), 3),
+                               "note": "train.train_step, no graph capture: host launch bound"}
+    # (2) the replayed step fed from pinned host memory through train.InputStager (copy of the next batch beside the replay)
+    if step_fn is not None:
+        host = {k: (v.detach().cpu().pin_memory() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        stager = InputStager(step_fn)
+        stager.submit(host)
+
+        def staged():
+            r = stager.run()
+            stager.submit(host)
+            return r
+        for _ in range(3):
+            staged()
+        ms = timed_steps(staged, 10)
+        stager.run()
+        out["staged_input_step"] = {"ms_per_step": round(ms, 3), "volumes_per_s": round(args.batch / ms * 1e3, 2),
+                                    "vs_resident_inputs": round(ms / headline_ms, 4),
+                                    "note": "hipGraph replay + host->device copy of the next batch (3 volumes + covariates + priors, "
+                                            "pinned) on a side stream + device-to-device hand-over"}
+    return out
+
+
+def secondary_config(size_dhw, dtype_name, batch, dev, steps=3, with_roofline=False):
+    """One more configuration through the graphed step: ms/step (+ the per-kernel roofline of 1 eager step)."""
+    import coma_unet_amd as cu
+    from coma_unet_amd import ops
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, make_optimizer, GraphedTrainStep
+    dt = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = cu.build_model(volume_shape=size_dhw, compute_dtype=dt, static_prompts=True).to(dev)
+    model.set_save_attn(None)
+    model.train(True)
+    crit = cu.build_reference_criterion(dev)
+    opt = make_optimizer(model, 1e-3)
+    b = make_batch(batch, size_dhw, seed=2000)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    gb["roi_pred_dicts"] = model._priors(b["roi_pred_dicts"], batch, dev)
+    step_fn = GraphedTrainStep(model, crit, opt, gb, warmup=2)
+    step_fn()
+    ms = timed_steps(lambda: step_fn(), steps)
+    vox = size_dhw[0] * size_dhw[1] * size_dhw[2]
+    unet_tf = UNET_TFLOP_PER_VOLUME_128 * vox / 128.0 ** 3
+    peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else FP32_VALU_PEAK_TFLOPS
+    res = {"ms_per_step": round(ms, 3), "volumes_per_s": round(batch / ms * 1e3, 3), "dtype": dtype_name, "batch": batch,
+           "volume": list(size_dhw), "loss": round(float(step_fn.losses[0]), 4),
+           "step": {"unet_tflop_per_volume": round(unet_tf, 4), "achieved_tflops": round(batch / ms * 1e3 * unet_tf, 2), "peak": peak,
+                    "frac": round(batch / ms * 1e3 * unet_tf / peak, 4)}}
+    if with_roofline:
+        ops.KernelTimer.enabled = True
+        ops.KernelTimer.records = []
+        train_step(model, crit, opt, gb, None)
+        torch.cuda.synchronize()
+        ops.KernelTimer.enabled = False
+        roof, rm, rh = rooflines(ops.KernelTimer.by_kernel(), 1, peak, res["step"], "HIP events around every conv / norm launch of 1 eager step")
+        res["roofline"], res["roofline_mfma"], res["roofline_hbm"] = roof, rm, rh
+        ops.KernelTimer.records = []
+    del step_fn, model, opt, crit
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -99,6 +217,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (eager step, staged inputs, fp32, C5)")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly even on one GPU")
     ap.add_argument("--dp", default=os.environ.get("COMA_DP", "torch"), choices=["torch", "capi", "capi-sharded"],
                     help="N > 1 gradient exchange: torch = torch.distributed (RCCL) all-reduce after the graph-replayed fwd+bwd; "
@@ -219,28 +338,13 @@ def main():
         step_ach = value * unet_tf
         step_roof = {"unet_tflop_per_volume": round(unet_tf, 4), "achieved_tflops": round(step_ach, 2), "peak": peak_tf,
                      "frac": round(step_ach / peak_tf, 4)}
+        roof_mfma = roof_hbm = None
         if summ:
             for (kind, algo), (n, ms, fl, by) in sorted(summ.items()):
                 kernels[f"{kind}/{algo}"] = {"launches": n, "ms_total": round(ms, 3),
                                              "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
                                              "alg_GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-            top = sorted(byk.items(), key=lambda kv: -kv[1][1])
-            kname, (n, ms, fl, by) = top[0]
-            thin = fl / max(by, 1.0) < 150.0      # below the MFMA/HBM ridge (~300 FLOP/B) by 2x: a bandwidth kernel
-            common = {"kernel": kname, "launches_per_step": n / timer_steps, "avg_launch_us": round(ms / n * 1e3, 2),
-                      "alg_flops_per_launch": round(fl / n), "alg_bytes_per_launch": round(by / n),
-                      "traffic": pmc_traffic(kname), "step": step_roof, "measured": timer_note,
-                      "top_kernels": [{"kernel": k, "launches_per_step": v[0] / timer_steps, "ms_per_step": round(v[1] / timer_steps, 3),
-                                       "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1), "alg_GBps": round(v[3] / (v[1] * 1e-3) / 1e9)}
-                                      for k, v in top[:8]]}
-            if thin:
-                ach = by / (ms * 1e-3) / 1e9
-                roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBPS, 4), **common}
-            else:
-                ach = fl / (ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
-                        "frac": round(ach / peak_tf, 4), **common}
+            roof, roof_mfma, roof_hbm = rooflines(byk, timer_steps, peak_tf, step_roof, timer_note)
         line = {
             "metric": f"volumes/sec (train fwd+bwd) at 128^3 {args.dtype}", "value": round(value, 4), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -256,8 +360,15 @@ def main():
                        "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 1)},
             "loss": round(loss, 4), "note": graph_note,
             "unet_tflops_per_s": round(step_ach, 2),
-            "roofline": roof, "conv_kernels": kernels,
+            "roofline": roof, "roofline_mfma": roof_mfma, "roofline_hbm": roof_hbm, "conv_kernels": kernels,
+            "zero_arena_mb": {str(k): round(a.peak / 2 ** 20, 1) for k, a in ops.ZeroArena._arenas.items()},
         }
+        if world == 1 and not args.no_secondary:
+            try:
+                line["secondary"] = secondary_figures(args, dev, elapsed / args.steps * 1e3,
+                                                      (model, crit, opt, batch, step_fn if use_graph else None))
+            except Exception as e:      # never lose the headline to a secondary measurement
+                line["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 threads = len(os.sched_getaffinity(0))
@@ -268,6 +379,15 @@ def main():
             if use_graph:
                 del step_fn, run_step
             torch.cuda.empty_cache()
+            if not args.no_secondary and isinstance(line.get("secondary"), dict) and "error" not in line["secondary"]:
+                for key, cfg in (("fp32_128", ((args.size,) * 3, "fp32", args.batch, 3, True)),
+                                 ("c5_fullres_fp32", ((192, 224, 192), "fp32", 1, 2, False))):
+                    if args.size != 128 and key == "c5_fullres_fp32":
+                        continue
+                    try:
+                        line["secondary"][key] = secondary_config(cfg[0], cfg[1], cfg[2], dev, steps=cfg[3], with_roofline=cfg[4])
+                    except Exception as e:
+                        line["secondary"][key] = {"error": f"{type(e).__name__}: {e}"}
             factory = lambda: (lambda mm: (mm.set_save_attn(None), mm)[1])(cu.build_model(volume_shape=S, compute_dtype=dt).to(dev))
             line["cpu_baseline"], line["parity"] = cpu_baseline(args.size, threads, args.batch, factory)
         else:

@@ -31,7 +31,8 @@ class KernelTimer:
     records = []   # (kind, algo, flops, ev_start, ev_end, layer tag, kernel name)
 
     @classmethod
-    def run(cls, kind, algo, flops, fn, tag=None):
+    def run(cls, kind, algo, flops, fn, tag=None, name=None):
+        """`name`: the kernel(s) of a call that does not go through the convolution dispatch (normalisation, gate)."""
         if not cls.enabled:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,7 +40,7 @@ class KernelTimer:
         r = fn()
         e1.record()
         # the kernel variant the library just launched, spelled as rocprofv3 prints it (coma_last_kernel)
-        cls.records.append((kind, algo, flops, e0, e1, tag, lib.coma_last_kernel().decode()))
+        cls.records.append((kind, algo, flops, e0, e1, tag, name if name is not None else lib.coma_last_kernel().decode()))
         return r
 
     @classmethod
@@ -741,9 +742,12 @@ class NormAct(Function):
             rstd = torch.rsqrt(rvar.reshape(1, C).float() + eps).contiguous()
         upd = sums is not None and rmean is not None and training and mode == L.NORM_BATCH
         y = out.t if out is not None else _new(x.shape, x.dtype, dev)
-        check(lib.coma_norm_act_fwd(cx, mode, ptr(sums), eps, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(slope),
-                                    ptr(rmean) if upd else None, ptr(rvar) if upd else None, momentum, ct(y), s),
-              "coma_norm_act_fwd")
+        tb = float(x.numel() * x.element_size())          # algorithmic bytes: one read + one write of the tensor
+        KernelTimer.run("norm_fwd", "hbm", (0.0, 2.0 * tb),
+                        lambda: check(lib.coma_norm_act_fwd(cx, mode, ptr(sums), eps, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act,
+                                                            ptr(slope), ptr(rmean) if upd else None, ptr(rvar) if upd else None,
+                                                            momentum, ct(y), s), "coma_norm_act_fwd"),
+                        name="norm_act_fwd_k<%s, %d>" % ("__bf16" if x.dtype == torch.bfloat16 else "float", 8 if (x.dtype == torch.bfloat16 and C % 8 == 0) else (4 if C % 4 == 0 else 1)))
         ctx.save_for_backward(x, sums, gamma, beta, slope)
         ctx.meta = (mode, act, use_batch_stats, eps)
         return y
@@ -763,9 +767,12 @@ class NormAct(Function):
         dbeta = sinks[1] if sinks[1] is not None else (_f32(C, dev) if beta is not None else None)
         dslope = sinks[2] if sinks[2] is not None else (_f32(1, dev) if slope is not None else None)
         bsums = stat_record(G, C, 3, dev)
-        check(lib.coma_norm_act_bwd(ct(x), ct(dy), mode, ptr(sums), eps, ptr(gamma), ptr(beta), act, ptr(slope),
-                                    ct(dx), ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(bsums), L.stream()),
-              "coma_norm_act_bwd")
+        tb = float(x.numel() * x.element_size())          # algorithmic bytes: (x, dy) read twice + dx written once
+        KernelTimer.run("norm_bwd", "hbm", (0.0, 5.0 * tb),
+                        lambda: check(lib.coma_norm_act_bwd(ct(x), ct(dy), mode, ptr(sums), eps, ptr(gamma), ptr(beta), act, ptr(slope),
+                                                            ct(dx), ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(bsums), L.stream()),
+                                      "coma_norm_act_bwd"),
+                        name="norm_bwd_partial_k + norm_act_bwd_apply_k<%s>" % ("__bf16" if x.dtype == torch.bfloat16 else "float"))
         return (dx, None if sinks[0] is not None else dgamma, None if sinks[1] is not None else dbeta,
                 None if sinks[2] is not None else dslope, None, None, None, None, None, None, None, None, None)
 

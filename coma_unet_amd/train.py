@@ -141,3 +141,55 @@ class GraphedTrainStep:
         else:
             self.reducer.reduce_flat_and_step()
         return self.losses, self.outputs
+
+
+class InputStager:
+    """Host -> device input staging beside the replayed step (SURVEY.md section 8 f-4 meets the step): the NEXT batch's
+    volumes are copied from pinned host buffers into a device staging set on a side HIP stream while the current step's
+    graph replays; `run()` then moves them into the graph's static input buffers with device-to-device copies (3 x 17 MB
+    at 128^3: ~30 us) on the compute stream and replays.  The reference's loader hands `train_dp` pageable CPU tensors
+    (VolumeDataset_ADNI_A4_combined.py:91) and `.cuda()`s them synchronously in front of every step
+    (attn_unet_data_parallel.py:789-804); this takes that copy off the critical path."""
+
+    def __init__(self, step: GraphedTrainStep):
+        self.step = step
+        dev = step.batch["mri"].device
+        self.stream = torch.cuda.Stream(device=dev)
+        self.dev = {k: torch.empty_like(v) for k, v in step.batch.items() if torch.is_tensor(v)}
+        self.pinned = {}
+        self.ready = None
+        self.consumed = None
+
+    def submit(self, host_batch):
+        """Queue the copies of the next batch (CPU tensors, pinned or pageable -- pageable ones go through a pinned
+        buffer of this object; device tensors are taken as they are)."""
+        if self.ready is not None:
+            raise RuntimeError("InputStager.submit: the previous batch has not been run yet")
+        with torch.cuda.stream(self.stream):
+            if self.consumed is not None:
+                self.stream.wait_event(self.consumed)          # the previous batch has left the staging set
+            for k, dst in self.dev.items():
+                src = host_batch[k]
+                if not torch.is_tensor(src):
+                    continue
+                if src.device.type == "cpu" and not src.is_pinned():
+                    buf = self.pinned.get(k)
+                    if buf is None or buf.shape != src.shape or buf.dtype != src.dtype:
+                        buf = self.pinned[k] = torch.empty(src.shape, dtype=src.dtype).pin_memory()
+                    self.stream.synchronize()                  # (the previous copy out of this pinned buffer is done)
+                    buf.copy_(src)
+                    src = buf
+                dst.copy_(src, non_blocking=True)
+            self.ready = torch.cuda.Event()
+            self.ready.record(self.stream)
+
+    def run(self):
+        """Replay the step on the submitted batch."""
+        assert self.ready is not None, "InputStager.run: submit() a batch first"
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.ready)
+        self.step.load(self.dev)
+        self.consumed = torch.cuda.Event()
+        self.consumed.record(cur)
+        self.ready = None
+        return self.step()
