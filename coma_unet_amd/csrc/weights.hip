@@ -206,6 +206,75 @@ __global__ __launch_bounds__(256) void weight_prep_bwd_k(const float* dwk, const
   }
 }
 
+// The same for 27-tap masters, with every master / dmaster access COALESCED: a block owns 256 consecutive (a, b) pairs of
+// the master layout = one contiguous run of 256 x 27 floats per expert.  The kernel-layout gradient of those pairs is
+// brought into master order ONCE (through LDS: lane = pair writes its 27 taps, lane = linear index reads them back), then
+// each expert is 27 fully coalesced loads (for dr) and 27 fully coalesced stores per lane.  (The per-pair kernel above
+// reads and writes 108-byte runs per lane: every dword instruction touches 64 different lines -- 2.7 TB/s; a first tiled
+// version that transposed per expert was slower still.)  transposed: master [c][n][27] (ConvTranspose3d), else [n][c][27].
+template <int BB>
+__global__ __launch_bounds__(256) void weight_prep_bwd27_k(const float* __restrict__ dwk, const float* __restrict__ master,
+                                                           const float* __restrict__ r, int E, int Bw, int N, int C, int64_t se,
+                                                           int transposed, float* __restrict__ dmaster, float* __restrict__ dr) {
+  __shared__ float T[BB][256 * 28];      // [sample][pair][27 taps, pitch 28]
+  __shared__ float red[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) red[tid] = 0.f;
+  const int64_t NC = (int64_t)N * C;
+  const int64_t j0 = (int64_t)blockIdx.x * 256;                 // first pair (master order) of this block
+  const int64_t j = j0 + tid;
+  if (j < NC) {
+    // pair j of the master -> (n, c) of the kernel layout dwk[b][tap][n][c]
+    const int64_t a = transposed ? j / N : j / C, bq = transposed ? j - a * N : j - a * C;
+    const int64_t i = transposed ? bq * C + a : a * C + bq;
+#pragma unroll
+    for (int b = 0; b < BB; ++b)
+#pragma unroll
+      for (int t = 0; t < 27; ++t) T[b][tid * 28 + t] = b < Bw ? dwk[((int64_t)b * 27 + t) * NC + i] : 0.f;
+  }
+  __syncthreads();
+  const int64_t nvalid = (NC - j0 < 256 ? NC - j0 : 256) * 27;   // floats of this block's run
+  float g[BB][27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int m = k * 256 + tid, pr = m / 27, tp = m - pr * 27;
+#pragma unroll
+    for (int b = 0; b < BB; ++b) g[b][k] = m < nvalid ? T[b][pr * 28 + tp] : 0.f;
+  }
+  for (int e = 0; e < E; ++e) {
+    const float* mp = master + e * se + j0 * 27;
+    float* dp = dmaster + e * se + j0 * 27;
+    float rb[BB], dot[BB];
+#pragma unroll
+    for (int b = 0; b < BB; ++b) { rb[b] = b < Bw ? (r ? r[b * E + e] : 1.f) : 0.f; dot[b] = 0.f; }
+    float w[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) { const int m = k * 256 + tid; w[k] = (dr && m < nvalid) ? mp[m] : 0.f; }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const int m = k * 256 + tid;
+      float dm = 0.f;
+#pragma unroll
+      for (int b = 0; b < BB; ++b) { dm = fmaf(rb[b], g[b][k], dm); dot[b] = fmaf(g[b][k], w[k], dot[b]); }
+      if (m < nvalid) dp[m] = dm;
+    }
+    if (dr) {
+#pragma unroll
+      for (int b = 0; b < BB; ++b) {
+        if (b < Bw) {
+          float d = dot[b];
+          for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+          if ((tid & 63) == 0) atomicAdd(&red[b * E + e], d);
+        }
+      }
+    }
+  }
+  if (dr) {
+    __syncthreads();
+    if (tid < Bw * E) atomicAdd(dr + tid, red[tid]);
+  }
+}
+
 extern "C" int coma_weight_prep_bwd(const float* dwk, const float* master, const float* r, int32_t E, int32_t Bw, int32_t N,
                                     int32_t C, int32_t taps, int64_t se, int64_t sn, int64_t sc, float* dmaster, float* dr,
                                     int32_t zeroed, void* stream) {
@@ -215,6 +284,13 @@ extern "C" int coma_weight_prep_bwd(const float* dwk, const float* master, const
   hipStream_t s = (hipStream_t)stream;
   if (dr && !(zeroed & COMA_ZEROED_OUT) && hipMemsetAsync(dr, 0, sizeof(float) * Bw * E, s) != hipSuccess) { coma_set_error("weight_prep_bwd: memset failed"); return 2; }
   dim3 grid((unsigned)(((int64_t)N * C + 255) / 256));
+  static const bool old_path = getenv("COMA_WPREP_BWD_OLD") != nullptr;      // (A/B measurements)
+  const bool plain = sc == 27 && sn == (int64_t)C * 27, transposed = sn == 27 && sc == (int64_t)N * 27;
+  if (taps == 27 && Bw <= 2 && (plain || transposed) && !old_path) {
+    hipLaunchKernelGGL((weight_prep_bwd27_k<2>), grid, dim3(256), 0, s, dwk, master, r, E, Bw, N, C, se, transposed ? 1 : 0, dmaster, dr);
+    COMA_LAUNCH_CHECK();
+    return 0;
+  }
 #define L(TP, BBV) hipLaunchKernelGGL((weight_prep_bwd_k<TP, BBV>), grid, dim3(256), 0, s, dwk, master, r, E, Bw, N, C, se, sn, sc, dmaster, dr)
   if (taps == 27) { if (Bw <= 2) L(27, 2); else if (Bw <= 4) L(27, 4); else L(27, 8); }
   else { if (Bw <= 2) L(1, 2); else if (Bw <= 4) L(1, 4); else L(1, 8); }
