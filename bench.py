@@ -266,9 +266,16 @@ def main():
             return None
         if args.dp == "torch":
             return GradReducer(opt)
+        if os.environ.get("COMA_DIST_BACKEND", "nccl") != "nccl":
+            # rehearsal of the capi modes without RCCL (several ranks on one GPU / gloo): the torch.distributed stand-in with
+            # the communicator's interface -- same bucket / shard logic, collectives not capturable (the step runs eagerly)
+            from coma_unet_amd.data_parallel import TorchComm
+            return StreamedGradExchange(opt, TorchComm(), sharded=args.dp == "capi-sharded")
         from coma_unet_amd.rccl_comm import RcclComm
         return StreamedGradExchange(opt, RcclComm(device=dev), sharded=args.dp == "capi-sharded")
     reducer = make_reducer()
+    if world > 1 and args.dp != "torch" and os.environ.get("COMA_DIST_BACKEND", "nccl") != "nccl":
+        args.no_graph = True
     b = make_batch(args.batch, S, seed=1000 + rank)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
     batch["roi_pred_dicts"] = model._priors(b["roi_pred_dicts"], args.batch, dev)   # (B,36,2) resident table
@@ -320,10 +327,53 @@ def main():
         ops.KernelTimer.enabled = False
         timer_note = "HIP events around every conv launch of 2 eager steps run right after the graph-replayed timed region"
     timer_steps = 2 if use_graph else args.steps
+    dp_info = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        # how much of the step is the gradient exchange, and how much of the exchange is exposed:
+        #   exchange_ms  one exchange of the whole flat gradient buffer with nothing beside it (the mode's own collectives)
+        #   local_ms     the same step without any exchange (each rank alone; run AFTER the timed region: the replicas may drift)
+        #   exposed_ms   ms_per_step - local_ms: what the exchange adds to the step after overlap
+        try:
+            sync_all()
+            def exchange_once():
+                if args.dp == "torch":
+                    reducer.reduce_flat()
+                elif args.dp == "capi":
+                    reducer.comm.all_reduce_(opt.flat_g)
+                else:
+                    n = opt.flat_g.numel() // world
+                    reducer.comm.reduce_scatter(opt.flat_g, opt.flat_g[reducer.comm.rank * n:(reducer.comm.rank + 1) * n])
+                    reducer.comm.all_gather(opt.flat_p[reducer.comm.rank * n:(reducer.comm.rank + 1) * n], opt.flat_p)
+            exchange_once()
+            sync_all()
+            t0x = time.perf_counter()
+            for _ in range(3):
+                exchange_once()
+            sync_all()
+            exchange_ms = (time.perf_counter() - t0x) / 3 * 1e3
+            if use_graph:
+                local = GraphedTrainStep(model, crit, opt, batch, warmup=2, reducer=None)
+                local_fn = lambda: local()
+            else:
+                local_fn = lambda: train_step(model, crit, opt, batch, None)
+            local_fn()
+            sync_all()
+            t0l = time.perf_counter()
+            for _ in range(5):
+                local_fn()
+            sync_all()
+            local_ms = (time.perf_counter() - t0l) / 5 * 1e3
+            tt = torch.tensor([exchange_ms, local_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dp_info = {"mode": args.dp, "exchange_ms": round(float(tt[0]), 3), "local_step_ms": round(float(tt[1]), 3),
+                       "exposed_ms": round(elapsed / args.steps * 1e3 - float(tt[1]), 3),
+                       "gradient_mb": round(opt.flat_g.numel() * 4 / 2 ** 20, 1),
+                       "early_buckets": getattr(reducer, "early", None)}
+        except Exception as e:
+            dp_info = {"mode": args.dp, "error": f"{type(e).__name__}: {e}"}
     loss = float(last[0])
 
     if rank == 0:
@@ -362,6 +412,7 @@ def main():
             "unet_tflops_per_s": round(step_ach, 2),
             "roofline": roof, "roofline_mfma": roof_mfma, "roofline_hbm": roof_hbm, "conv_kernels": kernels,
             "zero_arena_mb": {str(k): round(a.peak / 2 ** 20, 1) for k, a in ops.ZeroArena._arenas.items()},
+            "data_parallel": dp_info,
         }
         if world == 1 and not args.no_secondary:
             try:

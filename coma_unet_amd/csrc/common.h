@@ -54,7 +54,13 @@ template <> struct vec_io<bf16_t, 4> {
 };
 template <> struct vec_io<bf16_t, 8> {
   static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
+#ifdef COMA_NT_LOADS
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    const uint4 v = make_uint4(t[0], t[1], t[2], t[3]);
+#else
     const uint4 v = *reinterpret_cast<const uint4*>(p);
+#endif
     const unsigned u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(u[j] << 16); o[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u); }

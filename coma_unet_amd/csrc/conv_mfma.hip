@@ -1559,6 +1559,7 @@ struct PwP {
   const bf16_t* w; long wsb;
   const float* bias; int bsb;
   int st8;
+  int st16;            // output rows allow aligned 16-byte (8-channel) accesses
   double2* stats;      // optional fused {sum, sumsq} partials of the stored outputs, [chunk][G][N] (as conv_mfma_halo2_k)
   int stats_inst;
   int accum;           // y += conv(x)
@@ -1620,7 +1621,52 @@ __global__ __launch_bounds__(256) void conv_mfma_pw_k(PwP p) {
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][ks], xf[ks], acc, 0, 0, 0);
-      if (live) {
+      const int nval = p.N - j * 32 < 32 ? p.N - j * 32 : 32;
+      if (p.st16 && (nval & 15) == 0) {
+        // 16 or 32 valid channels: the two half-waves exchange 4-channel groups (v_permlane32_swap) so that a lane owns 8
+        // CONSECUTIVE channels per 16-channel half: one 16-byte store (and, accumulating, one 16-byte load) instead of two
+        // 8-byte ones -- 8-byte accesses run at 0.5-0.7 of the 16-byte rate, and the accumulate mode doubles them
+        bf16_t* vox = yb + v * p.ldy + j * 32 + 8 * fh;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          if (16 * gp >= nval) continue;                 // (wave-uniform)
+          float of[2][4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) of[h][q] = acc[(2 * gp + h) * 4 + q] + bv[j][2 * gp + h][q];
+          if (p.accum) {                                  // (wave-uniform) y += : see conv_mfma_tconv_k
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (live) u = *reinterpret_cast<const uint4*>(vox + 16 * gp);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(u.x, u.z, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(u.y, u.w, false, false);
+            const unsigned w0[2] = {s0[0], s1[0]}, w1[2] = {s0[1], s1[1]};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              of[0][2 * h] += __uint_as_float(w0[h] << 16); of[0][2 * h + 1] += __uint_as_float(w0[h] & 0xffff0000u);
+              of[1][2 * h] += __uint_as_float(w1[h] << 16); of[1][2 * h + 1] += __uint_as_float(w1[h] & 0xffff0000u);
+            }
+          }
+          unsigned pk[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            bf16_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              o[q] = static_cast<bf16_t>(of[h][q]);
+              if (do_stats) {
+                const float r = live ? static_cast<float>(o[q]) : 0.f;
+                st_s[j][2 * gp + h][q] += r; st_q[j][2 * gp + h][q] = fmaf(r, r, st_q[j][2 * gp + h][q]);
+              }
+            }
+            const uint2 u2 = *reinterpret_cast<const uint2*>(o);
+            pk[h][0] = u2.x; pk[h][1] = u2.y;
+          }
+          const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+          if (live) *reinterpret_cast<uint4*>(vox + 16 * gp) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+      } else if (live) {
         bf16_t* dst = yb + v * p.ldy + j * 32 + 4 * fh;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -2364,6 +2410,7 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
     q.w = (const bf16_t*)wk; q.wsb = d->per_sample_w ? (long)y->C * x->C : 0;
     q.bias = bias; q.bsb = d->per_sample_w ? y->C : 0;
     q.st8 = y->ld % 4 == 0 && y->sb % 4 == 0 && (((uintptr_t)y->data) & 7) == 0;
+    q.st16 = y->ld % 8 == 0 && y->sb % 8 == 0 && (((uintptr_t)y->data) & 15) == 0;
     const int ks = (x->C + 15) / 16, nt = (y->C + 31) / 32;
     long nb = ((q.V + 31) / 32 + 3) / 4;
     if (nb > 2048) nb = 2048;

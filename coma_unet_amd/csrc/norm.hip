@@ -435,9 +435,11 @@ static NormStat make_stat(const coma_tensor* x, int mode, const double* sums, fl
   return st;
 }
 
+static int norm_knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static unsigned ew_blocks(int64_t total, int per_thread) {
+  static const int cap = norm_knob("COMA_NORM_BLOCKS", 4096);
   int64_t nb = (total + 256 * (int64_t)per_thread - 1) / (256 * (int64_t)per_thread);
-  if (nb > 4096) nb = 4096;
+  if (nb > cap) nb = cap;
   return (unsigned)(nb < 1 ? 1 : nb);
 }
 // the apply kernels keep a thread on ONE channel group when the grid stride is a multiple of the groups per voxel

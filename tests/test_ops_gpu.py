@@ -837,7 +837,7 @@ def test_grad_fork_accumulates_in_kernel_epilogues(dtype):
     ops, L = _ops()
     from coma_unet_amd.layers import Config, Convolution
     torch.manual_seed(3)
-    C, B, dims = 32, 2, (8, 8, 32)
+    C, B, dims = 32, 2, (8, 16, 32)          # 4096 voxels: the 1x1x1 layer runs on conv_mfma_pw_k (bf16), 16-byte epilogue
     cfg = Config(compute_dtype=dtype)
     convs = [Convolution(cfg, C, 16, kernel_size=1, conv_only=True).cuda(), Convolution(cfg, C, 64, strides=2, conv_only=True).cuda(),
              Convolution(cfg, C, 32, conv_only=True).cuda()]
@@ -845,12 +845,13 @@ def test_grad_fork_accumulates_in_kernel_epilogues(dtype):
     xq = torch.randn((B, C, *dims), generator=g, dtype=torch.float64).to(dtype).double()
     xr = xq.clone().requires_grad_(True)
     tot = 0.0
-    gys = []
+    gys, yrs = [], []
     for cv in convs:
         w, b = cv.conv.weight.detach().double().cpu(), cv.conv.bias.detach().double().cpu()
         if dtype == torch.bfloat16:
             w = w.bfloat16().double()
         y = F.conv3d(xr, w, b, stride=cv.s, padding=(cv.k - 1) // 2)
+        yrs.append(y.detach())
         gys.append(torch.randn(y.shape, generator=g, dtype=torch.float64).to(dtype).double())
         tot = tot + (y * gys[-1]).sum()
     tot.backward()
@@ -858,6 +859,8 @@ def test_grad_fork_accumulates_in_kernel_epilogues(dtype):
     xf = ops.fork(xi)
     assert getattr(xf, "_coma_fork", None) is not None
     outs = [cv(xf) for cv in convs]
+    for o, yr in zip(outs, yrs):
+        assert rel(to_ext(o), yr) < TOL[dtype], rel(to_ext(o), yr)
     torch.autograd.backward(outs, [to_int(t).to("cuda", dtype) for t in gys])
     assert rel(to_ext(xi.grad), xr.grad) < 3 * TOL[dtype], rel(to_ext(xi.grad), xr.grad)
     assert xf._coma_fork.buf is None          # the meeting point was handed back
