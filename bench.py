@@ -92,7 +92,20 @@ def pmc_traffic(kernel_name):
     except Exception:
         return None
     ent = tab.get(kernel_name)
-    return ent if ent is None else float(ent["hbm_bytes_per_launch"])
+    if ent is not None:
+        return float(ent["hbm_bytes_per_launch"])
+    if " + " in kernel_name:      # a bracket that covers two launches (normalisation backward: partial sums + apply)
+        dt = "__bf16" if "__bf16" in kernel_name else "float"
+        tot = 0.0
+        for part in kernel_name.split(" + "):
+            base = part.split("<")[0].strip()
+            cands = [v for k, v in tab.items() if k.startswith(base + "<") and dt in k]
+            if not cands:
+                return None
+            tot += max(float(c["hbm_bytes_per_launch"]) for c in cands)      # (the widest-vector instantiation carries the large tensors)
+        return tot
+    return None
+
 
 def rooflines(byk, timer_steps, peak_tf, step_roof, timer_note):
     """(roofline, roofline_mfma, roofline_hbm) from KernelTimer.by_kernel(): per kernel name (launches, ms, flops, bytes)."""
