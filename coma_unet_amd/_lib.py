@@ -160,15 +160,17 @@ _WS = {}
 _WS_PINNED = set()      # devices whose scratch buffer's address is baked into a captured hipGraph
 
 
-def workspace(nbytes: int, device) -> torch.Tensor:
-    """Stream-ordered scratch buffer (grown on demand, one per device).  While a captured graph holds the buffer's
-    raw pointer in its kernel arguments (pin_workspace) the cached buffer is never replaced: a larger request gets a
-    one-off allocation instead, so replays keep writing into memory that is still theirs."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+def workspace(nbytes: int, device, lane: int = 0) -> torch.Tensor:
+    """Stream-ordered scratch buffer (grown on demand, one per device and `lane`: lane 1 belongs to the side stream of
+    ops.WgradSide, whose kernels run beside the current stream's).  While a captured graph holds the buffer's raw pointer
+    in its kernel arguments (pin_workspace) the cached buffer is never replaced: a larger request gets a one-off
+    allocation instead, so replays keep writing into memory that is still theirs."""
+    dev = (device.index if device.index is not None else torch.cuda.current_device())
+    key = (dev, lane)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         new = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        if buf is not None and key in _WS_PINNED:
+        if buf is not None and dev in _WS_PINNED:
             return new
         _WS[key] = buf = new
     return buf

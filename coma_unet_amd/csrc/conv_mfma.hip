@@ -552,6 +552,11 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
   constexpr bool F32 = EPB == 4;
   static_assert(!F32 || (VEC == 1 && OCC == 1 && RESIDENT == 2), "fp32: vector staging, one block per CU, per-chunk weights");
   constexpr bool THIN = RESIDENT == 1 && OCC == 2;      // the few-channel variant (one chunk per tile, two blocks per CU)
+#ifdef COMA_HALO2_NO_YREUSE
+  constexpr bool YREUSE = false;
+#else
+  constexpr bool YREUSE = !(EPB == 4) && CK == 32 && OCC == 1 && RESIDENT != 0;   // the thick bf16 variants (see the tap loop)
+#endif
   constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
   constexpr int CPR = CK / EPB, KS = CPR / 2;        // 16-byte pieces per row, fragment reads per tap and operand
   constexpr int P = CPR == 4 ? 80 : 48;               // LDS row pitch (bytes): 16 rows land on 16 distinct 16-B slots
@@ -775,6 +780,46 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
         STAMP_ADD(0, t0, t1); STAMP_ADD(1, t1, t1b); STAMP_ADD(2, t1b, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4);
         // LDS fragments are read one tap ahead into a second register set (hipcc otherwise issues each ds_read right
         // before the MFMA that consumes it and waits lgkmcnt(0): the full LDS latency on every MFMA at 1-2 waves/SIMD)
+        if constexpr (YREUSE) {
+          // The wave's two M-tiles are y-neighbours (rows y, y + 1 of one z): for a fixed (kz, kx) their three ky taps read
+          // halo rows y .. y + 3, four distinct fragments per K step instead of six -- 14 fragment reads per 12 MFMAs
+          // instead of 18 (the LDS array is the unit all four waves share: 1.5 ds_read_b128 per MFMA keeps it 75 % busy).
+          uint4 wg[2][3][KS], xr[2][4][KS];
+          auto rdg = [&](int g, int bf) {
+            const int kz = g / 3, kx = g % 3;
+            const int toff = (kz * HY * HX + kx) * P;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) xr[bf][r][ks] = *reinterpret_cast<const uint4*>(Hl + a_base[0] + toff + r * HX * P + ks * 32);
+#pragma unroll
+              for (int ky = 0; ky < 3; ++ky)
+                wg[bf][ky][ks] = *reinterpret_cast<const uint4*>(Wl + w_base + (kz * 9 + ky * 3 + kx) * 32 * P + ks * 32);
+            }
+          };
+          rdg(0, 0);
+#pragma unroll
+          for (int g = 0; g < 9; ++g) {
+            if (g + 1 < 9) rdg(g + 1, (g + 1) & 1);
+            pref_piece(3 * g); pref_piece(3 * g + 1); pref_piece(3 * g + 2);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = mma_piece(wg[g & 1][ky][ks], xr[g & 1][i + ky][ks], acc[i], T());
+#define COMA_SGB(mfma, ds, valu, vmem)                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, mfma, 0);                            \
+            if (ds) __builtin_amdgcn_sched_group_barrier(0x100, ds, 0);                      \
+            if (valu) __builtin_amdgcn_sched_group_barrier(0x006, valu, 0);                  \
+            if (vmem) __builtin_amdgcn_sched_group_barrier(0x020, vmem, 0);
+            COMA_SGB(1, 2, 4, 0) COMA_SGB(1, 2, 4, 0) COMA_SGB(1, 2, 4, 1) COMA_SGB(1, 1, 3, 0)
+            COMA_SGB(1, 1, 3, 0) COMA_SGB(1, 1, 3, 1) COMA_SGB(1, 1, 3, 0) COMA_SGB(1, 1, 3, 0)
+            COMA_SGB(1, 1, 3, 1) COMA_SGB(1, 1, 3, 0) COMA_SGB(1, 1, 0, 0) COMA_SGB(1, 0, 0, 0)
+#undef COMA_SGB
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
         uint4 wv[2][KS], xv[2][2][KS];
         auto rd = [&](int t, int bf) {
           const int toff = (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * P;
@@ -815,6 +860,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
+        }
         }
         STAMP(t5);
         STAMP_ADD(5, t4, t5);

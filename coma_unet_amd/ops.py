@@ -7,6 +7,7 @@ library on the current stream; none of them has a CPU or PyTorch fallback.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -348,6 +349,7 @@ class SidePrep:
         for key, st in cls._streams.items():
             torch.cuda.current_stream(key).wait_stream(st)
         cls._on = False
+        WgradSide.joined()
 
     @classmethod
     def buffers(cls, master, shape_f, fwd_dtype, shape_d, dgrad_dtype):
@@ -365,6 +367,53 @@ class SidePrep:
                 ent = (master, _new(shape_f, fwd_dtype, dev), _new(shape_d, dgrad_dtype, dev) if dgrad_dtype is not None else None)
             cls._bufs[key] = ent
         return ent[1], ent[2]
+
+
+class WgradSide:
+    """Weight gradients beside the data-gradient chain.  A layer's weight gradient (MFMA-bound, 1.7 + 0.9 + 0.9 ms per step
+    over the thick / strided / thin layers), the scatter of it to the experts and the routing backward feed nothing but the
+    optimizer, while the chain they sit in today -- data gradient, normalisation backward, gate backward -- is mostly
+    HBM-bound.  With the step's gradients written through to the flat buffer (``GradSink``) they run on SidePrep's second
+    HIP stream: forked where the layer's ``dy`` exists, joined before the optimizer (``SidePrep.join``); under hipGraph
+    capture a parallel branch of the graph.  Everything the side stream still reads is kept referenced until the join
+    (``keep``): an allocator block of this stream's pool must not be handed out again while a queued side kernel reads it.
+    Off for data-parallel overlap (``GradSink.listener``: bucket order is launch order there), for gradients that go
+    through autograd instead of a sink slot, and while ``KernelTimer`` brackets launches.  COMA_WGRAD_SIDE=0 disables it."""
+    enabled = os.environ.get("COMA_WGRAD_SIDE", "1") not in ("0", "")
+    keep = []
+    dirty = False        # the side stream holds work of this step that the current stream has not waited for
+    launched = 0         # weight gradients sent to the side stream so far (diagnostic / tests)
+
+    @classmethod
+    def usable(cls, dev, params):
+        """May this backward node launch on the side stream?  `params`: every parameter whose gradient it produces."""
+        if not cls.enabled or KernelTimer.enabled or GradSink.listener is not None or torch.device(dev).type != "cuda":
+            return False
+        for p in params:
+            if p is None:
+                continue
+            if not getattr(p, "_coma_sink", False) or p.grad is None or id(p) in GradSink.written:
+                return False
+        return True
+
+    @classmethod
+    def begin(cls, dev, entry, *tensors):
+        """The side stream waits for `entry` (an event of the current stream); `tensors` stay alive until the join, which
+        the first use in a backward pass queues for the END of that pass (the caller of backward() finds every gradient
+        complete on its stream, as without the side stream).  Returns the side stream."""
+        st = SidePrep.stream(dev)
+        st.wait_event(entry)
+        cls.keep.extend(t for t in tensors if t is not None)
+        cls.launched += 1
+        if not cls.dirty:
+            cls.dirty = True
+            torch.autograd.Variable._execution_engine.queue_callback(SidePrep.join)
+        return st
+
+    @classmethod
+    def joined(cls):
+        cls.keep.clear()
+        cls.dirty = False
 
 
 # --------------------------------------------------------------------------------------
@@ -476,6 +525,18 @@ class Routing(Function):
         B, NC = cov.shape
         E, N = r.shape[1], bias_e.shape[1]
         dev = cov.device
+        scope = contextlib.nullcontext()
+        if WgradSide.dirty:      # dr / dbm of this step were produced on the side stream (ConvLayer.backward)
+            if WgradSide.usable(dev, (Wr, br, be)):
+                WgradSide.keep.extend(t for t in (cov, r, dr, dbm) if t is not None)
+                scope = torch.cuda.stream(SidePrep.stream(dev))
+            else:
+                SidePrep.fence(dev)
+        with scope:
+            return Routing._backward(cov, r, bias_e, Wr, br, be, dr, dbm, B, NC, E, N, dev)
+
+    @staticmethod
+    def _backward(cov, r, bias_e, Wr, br, be, dr, dbm, B, NC, E, N, dev):
         sinks = GradSink.slots((Wr, br, be))      # one kernel writes all three: one flush, then three marks
         dWr = sinks[0] if sinks[0] is not None else _f32((E, NC), dev)
         dbr = sinks[1] if sinks[1] is not None else _f32((E,), dev)
@@ -515,14 +576,14 @@ def pick_algo(x_shape, x_dtype, n_out, ksize, stride, transposed, per_sample, de
     return a_f, a_d
 
 
-def _scratch(nbytes, device):
+def _scratch(nbytes, device, lane=0):
     """(buffer, zeroed flag): the convolution's scratch as a private zeroed arena slice when the step's arena is armed
-    (the library then skips its memset), else the shared stream-ordered workspace."""
+    (the library then skips its memset), else the shared stream-ordered workspace (of the side stream: lane 1)."""
     if nbytes > 0:
         z = ZeroArena.take(nbytes, device)
         if z is not None:
             return z, L.ZEROED_WS
-    return workspace(nbytes, device), 0
+    return workspace(nbytes, device, lane), 0
 
 
 def _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm):
@@ -553,14 +614,23 @@ def _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm):
     return y, sums
 
 
-def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_dx, need_dw, bias_mode, p_bias, fork=None):
+def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_dx, need_dw, bias_mode, p_bias, fork=None,
+              side=False):
     """-> dx, dwk (fp32, kernel layout), dbias (None when absent, written through, or identically zero).
     bias_mode: 0 no bias, 1 reduce dy over the voxels, 2 the bias feeds a mean-removing normalisation (its gradient is
     identically zero: exact zeros are returned instead of a reduction of rounding noise).
-    fork: the input's GradFork -- the data gradient is written / accumulated into the shared buffer and dx is None."""
+    fork: the input's GradFork -- the data gradient is written / accumulated into the shared buffer and dx is None.
+    side: the weight gradient is launched on the side stream (WgradSide), forked at the ENTRY of this call -- it does not
+    wait for the data gradient; dwk / dbias are then valid on that stream only."""
     dx = dwk = dbias = None
     s = L.stream()
     tag = (tuple(x.shape), dy.shape[4], ksize, stride, form)
+    entry = None
+    if side and need_dw:
+        # forked HERE, not behind the data gradient: measured 18.3-18.6 ms per step against 19.1-19.2 (= no gain at all) when
+        # the weight gradient waits for its layer's data gradient
+        entry = torch.cuda.Event()
+        entry.record(torch.cuda.current_stream(x.device))
     if need_dx:
         assert wk_d is not None, "data gradient requested but dgrad weights were not prepared"
         dd, cdy_ = _desc(ksize, stride, 1 - form, per_sample, algo), ct(dy)
@@ -582,35 +652,41 @@ def _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, need_d
         if shared:
             dx = None
     if need_dw:
-        d = _desc(ksize, stride, form, per_sample, algo)
-        cx, cdy = ct(x), ct(dy)
-        # scratch: the replicas the kernels merge into must be zero -- a private arena slice of just that size when the
-        # step's arena is armed (a bias reduction writes its partial rows into the scratch first: shared workspace then)
-        nzs = lib.coma_conv_wgrad_zs_bytes(d, cx, cdy) if bias_mode != 1 else 0
-        ws, zf = _scratch(nzs, x.device) if nzs > 0 else (None, 0)
-        if not zf:
-            ws = workspace(lib.coma_conv_wgrad_ws_bytes(d, cx, cdy), x.device)
-        nel = 1
-        for k_ in wshape:
-            nel *= k_
-        dwk = ZeroArena.take(4 * nel, x.device, torch.float32)
-        if dwk is not None:
-            dwk, zf = dwk.view(wshape), zf | L.ZEROED_OUT
-        else:
-            dwk = _f32(wshape, x.device)
-        bshape = (x.shape[0], wshape[2]) if per_sample else (wshape[2],)
-        dbias_k = None
-        if bias_mode == 1:
-            sink = GradSink.slot(p_bias)
-            dbias_k = sink if sink is not None else _f32(bshape, x.device)
-            dbias = None if sink is not None else dbias_k
-        elif bias_mode == 2 and not per_sample:   # (per-sample: the routing node receives None = zero)
-            sink = GradSink.slot(p_bias)          # the flat gradient buffer was zeroed by zero_grad(): nothing to write
-            dbias = None if sink is not None else torch.zeros(bshape, dtype=torch.float32, device=x.device)
-        walgo = conv_class(_ALGO_NAMES[lib.coma_conv_wgrad_algo(d, cx, cdy)] if KernelTimer.enabled else "", x.shape[4], dy.shape[4])
-        KernelTimer.run("conv_wgrad", walgo, conv_flops(x.shape, dy.shape, ksize, stride),
-                        lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias_k), ptr(ws), ws.numel(), zf, s),
-                                      "coma_conv_wgrad"), tag=tag)
+        lane = 0
+        scope = contextlib.nullcontext()
+        if entry is not None:
+            scope, lane = torch.cuda.stream(WgradSide.begin(x.device, entry, x, dy)), 1
+        with scope:
+            s = L.stream()
+            d = _desc(ksize, stride, form, per_sample, algo)
+            cx, cdy = ct(x), ct(dy)
+            # scratch: the replicas the kernels merge into must be zero -- a private arena slice of just that size when the
+            # step's arena is armed (a bias reduction writes its partial rows into the scratch first: shared workspace then)
+            nzs = lib.coma_conv_wgrad_zs_bytes(d, cx, cdy) if bias_mode != 1 else 0
+            ws, zf = _scratch(nzs, x.device, lane) if nzs > 0 else (None, 0)
+            if not zf:
+                ws = workspace(lib.coma_conv_wgrad_ws_bytes(d, cx, cdy), x.device, lane)
+            nel = 1
+            for k_ in wshape:
+                nel *= k_
+            dwk = ZeroArena.take(4 * nel, x.device, torch.float32)
+            if dwk is not None:
+                dwk, zf = dwk.view(wshape), zf | L.ZEROED_OUT
+            else:
+                dwk = _f32(wshape, x.device)
+            bshape = (x.shape[0], wshape[2]) if per_sample else (wshape[2],)
+            dbias_k = None
+            if bias_mode == 1:
+                sink = GradSink.slot(p_bias)
+                dbias_k = sink if sink is not None else _f32(bshape, x.device)
+                dbias = None if sink is not None else dbias_k
+            elif bias_mode == 2 and not per_sample:   # (per-sample: the routing node receives None = zero)
+                sink = GradSink.slot(p_bias)          # the flat gradient buffer was zeroed by zero_grad(): nothing to write
+                dbias = None if sink is not None else torch.zeros(bshape, dtype=torch.float32, device=x.device)
+            walgo = conv_class(_ALGO_NAMES[lib.coma_conv_wgrad_algo(d, cx, cdy)] if KernelTimer.enabled else "", x.shape[4], dy.shape[4])
+            KernelTimer.run("conv_wgrad", walgo, conv_flops(x.shape, dy.shape, ksize, stride),
+                            lambda: check(lib.coma_conv_wgrad(d, cx, cdy, ptr(dwk), ptr(dbias_k), ptr(ws), ws.numel(), zf, s),
+                                          "coma_conv_wgrad"), tag=tag)
     return dx, dwk, dbias
 
 
@@ -694,12 +770,23 @@ class ConvLayer(Function):
         x, wk_d, master, rr = ctx.saved_tensors
         ksize, stride, form, per_sample, algo, bias_mode, wshape, pmeta = ctx.meta
         need_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        # weight gradient + expert scatter beside the data-gradient chain (WgradSide): when the master's (and a plain
+        # bias's) gradient is written through to the flat buffer -- a per-sample bias's goes to the routing node, which
+        # follows onto the side stream
+        wside = need_dw and WgradSide.usable(x.device, (ctx.p_master, ctx.p_bias if bias_mode else None))
         dx, dwk, dbias = _conv_bwd(x, wk_d, dy, ksize, stride, form, per_sample, algo, wshape, ctx.needs_input_grad[0],
-                                   need_dw, bias_mode, ctx.p_bias, ctx.fork)
+                                   need_dw, bias_mode, ctx.p_bias, ctx.fork, wside)
         dmaster = dr = None
         if ctx.side:
             SidePrep._live = max(0, SidePrep._live - 1)
-        if need_dw:
+        if wside:
+            WgradSide.keep.extend((master, rr))
+            with torch.cuda.stream(SidePrep.stream(x.device)):
+                dmaster, dr = _prep_bwd(dwk, master, rr, pmeta, ctx.p_master)
+            WgradSide.keep.extend(t for t in (dwk, dr, dbias) if t is not None)
+        elif need_dw:
+            if WgradSide.dirty:       # (a gradient that goes through autograd after all: nothing of it may overtake the side stream)
+                SidePrep.fence(x.device)
             # the scatter to the experts runs on the side stream when its result is written through to the flat gradient
             # buffer (nothing on this stream reads it before the optimizer) and the routing node -- the only consumer of
             # dr -- itself lives on the side stream

@@ -5,6 +5,8 @@ filter), logging and the per-sample ``.item()`` bookkeeping of :892-910 are the 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops

@@ -1,0 +1,9 @@
+# thick stride-1 kernels, A/B of two builds: bash profiles/mb_halo2.sh [other-lib.so]
+cd $GRAFT_REPO_ROOT
+for cfg in "64 32 128" "32 32 128" "128 64 64" "64 64 64" "256 128 32"; do
+  set -- $cfg
+  for what in fwd dgrad; do
+    echo "== $1 -> $2 at $3^3 $what"; python profiles/microbench_conv.py --cin $1 --cout $2 --size $3 --per-sample --what $what | tail -1
+    if [ -n "$OTHER" ]; then echo "   other lib:"; COMA_UNET_LIB=$OTHER python profiles/microbench_conv.py --cin $1 --cout $2 --size $3 --per-sample --what $what | tail -1; fi
+  done
+done

@@ -413,6 +413,65 @@ def test_side_stream_weight_preparation_equals_one_stream():
         assert rel(g, ref_g) < 5e-3 and torch.equal(p_, ref_p), (mode, rel(g, ref_g))      # (norm / loss reductions use fp32 atomics)
 
 
+def test_side_stream_weight_gradients_equal_one_stream():
+    """ops.WgradSide: weight gradients, expert scatters and routing backward on the second HIP stream (eager, as a parallel
+    branch of the captured graph, and under a bare ``loss.backward()`` whose caller reads the gradients right away) must
+    give the gradients and parameters of the one-stream order -- on the deterministic direct kernels (conv_algo=1), where a
+    missing stream dependency or a buffer handed out too early shows as a mismatch."""
+    import coma_unet_amd as cu
+    from coma_unet_amd import ops
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, forward_loss, make_optimizer, GraphedTrainStep
+    S = (32, 32, 32)
+    b = make_batch(2, S, seed=35)
+    res = {}
+    was = ops.WgradSide.enabled
+    try:
+        for mode in ("one-stream", "side", "side-graph", "side-bare"):
+            ops.WgradSide.enabled = mode != "one-stream"
+            n0 = ops.WgradSide.launched
+            torch.manual_seed(9)
+            gm = cu.build_model(volume_shape=S, static_prompts=True, conv_algo=1).cuda()
+            gm.set_save_attn(None)
+            gm.train(True)
+            gb = _gpu_batch(b)
+            gb["roi_pred_dicts"] = gm._priors(b["roi_pred_dicts"], 2, torch.device("cuda"))
+            opt = make_optimizer(gm, 0.0)        # lr 0 (weight decay acts through lr too): every step sees the same parameters
+            crit = cu.build_reference_criterion()
+            losses = []
+            if mode == "side-graph":
+                step = GraphedTrainStep(gm, crit, opt, gb, warmup=2)        # 2 eager warm-up steps, then replays
+                for _ in range(2):
+                    losses.append(float(step()[0][0]))
+                g = opt.flat_g.clone()
+            elif mode == "side-bare":
+                for _ in range(2):
+                    train_step(gm, crit, opt, gb)
+                opt.zero_grad()
+                ls, _ = forward_loss(gm, crit, gb)
+                ls[0].backward()
+                g = opt.flat_g.clone()       # on the current stream, right behind backward(): the join was queued by the pass
+                assert not ops.WgradSide.dirty and not ops.WgradSide.keep
+                losses = [float(ls[0])]
+            else:
+                for _ in range(4):
+                    losses.append(float(train_step(gm, crit, opt, gb)[0][0]))
+                g = opt.flat_g.clone()
+            torch.cuda.synchronize()
+            used = ops.WgradSide.launched - n0
+            assert (used == 0) if mode == "one-stream" else (used >= 40), (mode, used)
+            res[mode] = (losses, g, opt.flat_p.clone())
+    finally:
+        ops.WgradSide.enabled = was
+    ref_l, ref_g, ref_p = res["one-stream"]
+    for mode in ("side", "side-graph", "side-bare"):
+        l, g, p_ = res[mode]
+        print(mode, l, "vs", ref_l)
+        for a in l:
+            assert abs(a - ref_l[0]) <= 1e-5 * abs(ref_l[0]), (mode, l, ref_l)
+        assert rel(g, ref_g) < 5e-3 and torch.equal(p_, ref_p), (mode, rel(g, ref_g))      # (norm / loss reductions use fp32 atomics)
+
+
 def _grad_scale(model):
     return {n: (float(p.grad.abs().max()) if p.grad is not None else 0.0) for n, p in model.named_parameters()}
 
