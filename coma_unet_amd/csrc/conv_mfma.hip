@@ -1051,6 +1051,326 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
 }
 
 // =====================================================================================
+// conv_mfma_duo_k -- the thick stride-1 3x3x3 kernel as TWO 4-wave groups per CU that alternate roles every phase.
+// conv_mfma_halo2_k runs one 4-wave block per CU, and its phases do not overlap: stamped, the MFMA loop is 55 % of the
+// kernel, LDS staging stores 18 %, the epilogue 13 %, barriers and waits 14 % -- the matrix pipe idles 45 % of the time.
+// Here a workgroup has 8 waves = 2 groups (each SIMD holds one wave of either group).  In a phase one group runs the 54
+// MFMAs of a (tile, 16-channel chunk) step out of ITS halo image while the other group does everything else for its own
+// next step: writes the halo chunk it fetched two phases ago into its image, writes its half of the next chunk's weights,
+// finishes a completed tile (bias, rounding, statistics, 16-byte stores) and issues the loads of the step after next.  One
+// workgroup barrier per phase; the loads stay in flight across barriers (raw s_barrier behind an LDS-only wait).
+//   LDS: 2 halo images of 816 rows x 48 B (16 channels + pad: 16 consecutive rows land on 16 distinct 16-byte slots)
+//        + 2 weight images of 27 taps x 64 lanes x 16 B in FRAGMENT order (a wave's read is 1 KB contiguous) = 130.5 KB.
+//   The two groups walk alternate tiles of the block's run and the same chunk sequence, so a weight image serves both
+//   (phases 2s and 2s + 1) while the other one is refilled, half by either group.  C == 32: the two images hold the
+//   layer's two chunks for the whole kernel.
+//   A wave's two M-tiles are y-neighbours: for a fixed (kz, kx) their three ky taps read four distinct halo rows, so a
+//   (kz, kx) group is 4 + 3 fragment reads for 6 MFMAs.
+// =====================================================================================
+__device__ __forceinline__ void duo_barrier() {
+  // LDS traffic of this wave has landed; buffer loads issued for later phases stay in flight (no vmcnt wait)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int STATS>
+__global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
+  constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
+  constexpr int P = 48, HB = HV * P, WB = 27 * 64 * 16;
+  constexpr int HP = HV * 2, HIT = (HP + 255) / 256;        // halo pieces of a 16-channel chunk; per thread of a group
+  constexpr int WH = 27 * 32, WIT = (WH + 255) / 256;       // weight pieces per half image; per thread of a group
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // the wave index through readfirstlane: everything derived from it (group, tile walk, descriptors, role branches) is
+  // then provably wave-uniform -- otherwise the compiler wraps every buffer load in a waterfall loop
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wid >> 2, wq = wid & 3, gt = tid & 255;
+  char* const Hl = smem + grp * HB;
+  char* const Wl = smem + 2 * HB;
+  const int b = blockIdx.z, n0 = blockIdx.y * 32;
+  const int fr = lane & 31, fh = lane >> 5;
+  const bf16_t* xb = static_cast<const bf16_t*>(p.x) + (long)b * p.sbx;
+  const bf16_t* wb = static_cast<const bf16_t*>(p.w) + (long)b * p.wsb;
+  bf16_t* yb = static_cast<bf16_t*>(p.y) + (long)b * p.sby;
+  const int nch = p.C >> 4;
+  const bool w_static = nch <= 2;
+
+  // ---- staging descriptors ----
+  unsigned h_roff[HIT], h_zyx[HIT];
+#pragma unroll
+  for (int it = 0; it < HIT; ++it) {
+    const int piece = gt + 256 * it, row = piece >> 1, half = piece & 1;
+    const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
+    h_zyx[it] = piece < HP ? ((unsigned)hz << 20) | ((unsigned)hy << 10) | (unsigned)hx : 0x1ff7fdffu;      // (invalid: above any limit)
+    h_roff[it] = (unsigned)((((hz * p.H + hy) * p.W + hx) * p.ldx + half * 8) * 2);
+  }
+  // in-volume test of a halo piece as two packed subtractions (fields of 9 bits under a guard bit each): halo coordinate h
+  // of a tile at origin o is inside iff lo <= h <= hi with lo = (o == 0), hi = min(dim - o, 510) per axis
+  constexpr unsigned GUARD = (1u << 29) | (1u << 19) | (1u << 9);
+  const int h_lds0 = (gt >> 1) * P + (gt & 1) * 16;          // + it * 128 * P
+  constexpr unsigned OOB = 0x7fff0000u;
+  const int w_half = grp == 1 ? 0 : WH;                       // group 1 fills pieces [0, WH), group 0 [WH, 2 WH)
+  // weight piece q = w_half + gt + 256 it = (tap, lane): tap = q >> 6 advances by 4 per `it`, the lane part is a per-thread
+  // constant -- its global offset is rebuilt at every fetch (a handful of VALU on the staging wave; registers are the
+  // scarce thing at two waves per SIMD)
+  const int w_q0 = w_half + gt;
+  const unsigned w_lane_b = (unsigned)((((n0 + (w_q0 & 31)) * p.C) + ((w_q0 >> 5) & 1) * 8) * 2);
+  const int w_lds0 = w_q0 * 16;                               // + it * 4096
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xb), 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wb), 0, p.wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xb), 0, 0, 0x00020000);   // reads as zero
+
+  // fragment bases: this wave's M-tiles are rows y0, y0 + 1 of plane zq
+  const int zq = wq >> 1, y0w = (wq & 1) * 2;
+  const int a_base = ((zq * HY + y0w) * HX + fr) * P + fh * 16;
+  const int w_frag = lane * 16;
+
+  // ---- this group's tile walk ----
+  const int id_begin = xcd_remap(blockIdx.x, gridDim.x) * p.ids_per_block;
+  int id_end = id_begin + p.ids_per_block;
+  if (id_end > p.ids_total) id_end = p.ids_total;
+  struct Cur { int valid, cc, tix, tiy, tiz, id; };
+  auto first_tile = [&](Cur& c, int from) {        // first valid id >= from with the group's parity relative to id_begin
+    c.cc = 0; c.valid = 0; c.tix = c.tiy = c.tiz = 0;
+    int id = from;
+    while (id < id_end && !tile_coords(id, p.ntx, p.nty, p.ntz, c.tix, c.tiy, c.tiz)) id += 2;
+    c.id = id;
+    c.valid = id < id_end;
+  };
+  auto advance = [&](Cur& c) {
+    if (!c.valid) return;
+    if (c.cc + 1 < nch) { ++c.cc; return; }
+    first_tile(c, c.id + 2);
+  };
+  // tiles of the two groups: count them (the phase count must be the same for every wave of the block)
+  int nt0 = 0, nt1 = 0;
+  {
+    int a, bq, c;
+    for (int id = id_begin; id < id_end; ++id)
+      if (tile_coords(id, p.ntx, p.nty, p.ntz, a, bq, c)) { if ((id - id_begin) & 1) ++nt1; else ++nt0; }
+  }
+  const int nsteps = (nt0 > nt1 ? nt0 : nt1) * nch;
+  if (nsteps == 0) return;
+  const int nphases = 2 * nsteps + 2;                // + 1 round: group 1's last tile is finished in a staging phase
+
+  // (native 4-dword vectors: as HIP uint4 structs the loop-carried pieces were split into scalars, the loads landed in
+  // temporaries and the copies into the carried registers put an s_waitcnt vmcnt(0) in front of every barrier)
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t hreg[HIT], wreg[WIT];
+  auto load_halo = [&](const Cur& c) {
+    const int z0 = c.tiz * TZ, y0 = c.tiy * TY, x0 = c.tix * TX;
+    const int zb = z0 - 1, yb0 = y0 - 1, xb0 = x0 - 1;
+    const unsigned org_b = (unsigned)((((long)(zb * p.H + yb0) * p.W + xb0) * p.ldx + c.cc * 16) * 2);
+    const __amdgpu_buffer_rsrc_t rs = c.valid ? rs_x : rs_0;
+    const unsigned lo = ((unsigned)(z0 == 0) << 20) | ((unsigned)(y0 == 0) << 10) | (unsigned)(x0 == 0);
+    const int hz_ = p.D - z0 < 510 ? p.D - z0 : 510, hy_ = p.H - y0 < 510 ? p.H - y0 : 510, hx_ = p.W - x0 < 510 ? p.W - x0 : 510;
+    const unsigned hi = (((unsigned)hz_ << 20) | ((unsigned)hy_ << 10) | (unsigned)hx_) | GUARD;
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      const bool ok = ((((h_zyx[it] | GUARD) - lo) & (hi - h_zyx[it])) & GUARD) == GUARD;
+      const unsigned voff = ok ? org_b + h_roff[it] : OOB;
+      hreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it)
+      if (gt + 256 * it < HP) *reinterpret_cast<u32x4_t*>(Hl + h_lds0 + it * 128 * P) = hreg[it];
+  };
+  auto load_w = [&](int ws, bool on) {               // this group's half of weight step ws (chunk ws % nch)
+    const int c0_b = (ws % nch) * 32;
+    const __amdgpu_buffer_rsrc_t rs = on ? rs_w : rs_0;
+    const unsigned tap_b = (unsigned)(p.N * p.C * 2);
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int tap = (w_q0 >> 6) + 4 * it;
+      const int wt = p.flip ? 26 - tap : tap;
+      const unsigned voff = (gt + 256 * it < WH) ? (unsigned)wt * tap_b + w_lane_b : OOB;
+      wreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, c0_b, 0);
+    }
+  };
+  auto store_w = [&](int ws) {
+    char* dst = Wl + (ws & 1) * WB + w_lds0;
+#pragma unroll
+    for (int it = 0; it < WIT; ++it)
+      if (gt + 256 * it < WH) *reinterpret_cast<u32x4_t*>(dst + it * 4096) = wreg[it];
+  };
+  auto w_needed = [&](int ws) { return ws < 2 || !w_static; };
+
+  f32x16_t acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  float st_s[4][4], st_q[4][4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { st_s[g4][q] = 0.f; st_q[g4][q] = 0.f; }
+  float* const bias_l = reinterpret_cast<float*>(smem + 2 * HB + 2 * WB);      // this block's 32 bias values (read at every tile end)
+  if (tid < 32) bias_l[tid] = p.bias ? p.bias[b * p.bsb + n0 + tid] : 0.f;
+
+  // ---- prologue: weight step 0 complete, group 0's first halo in place, the next loads in flight ----
+  Cur cC, cB, cA;            // computed last / fetched (to be stored next) / to fetch next
+  cC.valid = 0; cC.cc = 0; cC.tix = cC.tiy = cC.tiz = 0; cC.id = 0;
+  first_tile(cB, id_begin + grp);
+  cA = cB; advance(cA);
+  load_halo(cB);
+  load_w(0, true);
+  store_w(0);
+  if (grp == 0) {
+    store_halo();
+    cC = cB; cB = cA; advance(cA);
+    load_halo(cB);
+  }
+  load_w(1, w_needed(1));
+  duo_barrier();
+
+  // ================= matrix phase: step ph >> 1 of this group =================
+  auto matrix_phase = [&](int ph) __attribute__((always_inline)) {
+#ifdef COMA_DUO_NO_MFMA          // (diagnostic builds only: profiles/ablate_duo.sh)
+      return;
+#endif
+      if (cC.valid) {
+        if (cC.cc == 0) {          // a new tile (zeroed here, in place: zeroing in the epilogue made the compiler keep a second copy)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        }
+        const char* Wc = Wl + ((ph >> 1) & 1) * WB + w_frag;
+        uint4 wg[2][3], xr[2][4];
+        auto rdg = [&](int g, int bf) {
+          const int kz = g / 3, kx = g % 3;
+          const int toff = (kz * HY * HX + kx) * P;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xr[bf][r] = *reinterpret_cast<const uint4*>(Hl + a_base + toff + r * HX * P);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) wg[bf][ky] = *reinterpret_cast<const uint4*>(Wc + (kz * 9 + ky * 3 + kx) * 1024);
+        };
+        rdg(0, 0);
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+          if (g + 1 < 9) rdg(g + 1, (g + 1) & 1);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = mma_piece(wg[g & 1][ky], xr[g & 1][i + ky], acc[i], bf16_t());
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+  };
+  // ================= everything else, for this group's NEXT matrix phase =================
+  auto other_phase = [&](int ph) __attribute__((always_inline)) {
+#ifdef COMA_DUO_NO_STAGE
+      if (cC.valid && cC.cc == nch - 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(acc[i]));
+      }
+      cC = cB; cB = cA; advance(cA);
+      return;
+#endif
+      store_halo();                                     // (waits for the pieces fetched two phases ago)
+      const int ws = (ph >> 1) + 1;
+      if (w_needed(ws)) store_w(ws);
+      // every piece fetched two phases ago has been consumed (or, masked off, may be dropped): say so -- a piece stored under
+      // a lane mask or a skipped weight refill stays "in flight" for the waitcnt pass, which then drains vmcnt in front of
+      // the next fetch AND at the start of the next matrix phase
+      __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): free at run time, the pieces are two phases old
+      // finish the tile whose last chunk this group computed in the previous phase
+#ifdef COMA_DUO_NO_EPI
+      if (cC.valid && cC.cc == nch - 1) {          // (diagnostic: the accumulators stay live, nothing is stored)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(acc[i]));
+      }
+#else
+      if (cC.valid && cC.cc == nch - 1) {
+        const int x0 = cC.tix * TX, y0 = cC.tiy * TY, z0 = cC.tiz * TZ;
+        float4 bq[4];                                 // this lane's 16 bias values, four LDS reads in flight together
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) bq[g4] = *reinterpret_cast<const float4*>(bias_l + 8 * g4 + 4 * fh);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int j = wq * 2 + i;
+          const int gz = z0 + (j >> 2), gy = y0 + (j & 3), gx = x0 + fr;
+          const bool valid = gz < p.D && gy < p.H && gx < p.W;
+          unsigned pk[4][2];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            bf16_t o[4];
+            const float bv[4] = {bq[g4].x, bq[g4].y, bq[g4].z, bq[g4].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              o[q] = static_cast<bf16_t>(acc[i][g4 * 4 + q] + bv[q]);
+              if constexpr (STATS) {
+                const float r = valid ? static_cast<float>(o[q]) : 0.f;
+                st_s[g4][q] += r; st_q[g4][q] = fmaf(r, r, st_q[g4][q]);
+              }
+            }
+            const uint2 u = *reinterpret_cast<const uint2*>(o);
+            pk[g4][0] = u.x; pk[g4][1] = u.y;
+          }
+          bf16_t* vox = yb + ((long)(gz * p.H + gy) * p.W + gx) * p.ldy + n0 + 8 * fh;
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
+            if (valid) *reinterpret_cast<uint4*>(vox + 16 * gp) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#endif
+      // rotate the walk and fetch the step after next
+      cC = cB; cB = cA; advance(cA);
+      load_halo(cB);
+      if (w_needed(ws + 1)) load_w(ws + 1, true);
+  };
+  // Two straight-line loops, one per role order (NOT one loop with a role branch: the pieces in flight are loop-carried
+  // registers, and across a branch the compiler parked the loads in temporaries and copied them behind an s_waitcnt
+  // vmcnt(0) -- in front of every barrier).  Both loops execute two barriers per round.
+  // Enter the loops with nothing in flight: the waitcnt pass merges the prologue's pending loads (other registers than the
+  // loop's) into the loop header state and then waits vmcnt(0) wherever the loop body reuses one of those registers --
+  // at the start of every matrix phase.  (The builtin, not inline asm: the pass has to see this wait.)
+  __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only
+  if (grp == 0) {
+#pragma unroll 1
+    for (int ph = 0; ph < nphases; ph += 2) { matrix_phase(ph); duo_barrier(); other_phase(ph + 1); duo_barrier(); }
+  } else {
+#pragma unroll 1
+    for (int ph = 0; ph < nphases; ph += 2) { other_phase(ph); duo_barrier(); matrix_phase(ph + 1); duo_barrier(); }
+  }
+
+  // ---- fused statistics: lanes -> wave -> block (LDS) -> the caller's record ----
+  if constexpr (STATS) {
+    if (p.stats) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);      // [8 waves][32 ch][2]
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float a = st_s[g4][q], c = st_q[g4][q];
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+          if (fr == 0) { red[(wid * 32 + 8 * g4 + 4 * fh + q) * 2] = a; red[(wid * 32 + 8 * g4 + 4 * fh + q) * 2 + 1] = c; }
+        }
+      __syncthreads();
+      if (tid < 32 && n0 + tid < p.N) {
+        double a = 0.0, c = 0.0;
+        for (int w = 0; w < 8; ++w) { a += (double)red[(w * 32 + tid) * 2]; c += (double)red[(w * 32 + tid) * 2 + 1]; }
+        const int g = p.stats_inst ? b : 0;
+        stat_add(p.stats, p.stats_inst ? p.stats_inst : 1, p.N, g, n0 + tid, a, c);
+      }
+    }
+  }
+}
+
+// =====================================================================================
 // conv_thin16_k -- stride-1 3x3x3 convolution (forward, and data-gradient via `flip`) of the few-channel full-resolution
 // layers (C <= 16 input channels, N <= 32 output channels: the prompt / UQ tail 3->16->16->1, 2->8->8->1, the 1->32 head
 // convolution and their data-gradients), W >= 32.  These layers are bandwidth-bound (2 (C + N) bytes per voxel); on the
@@ -2360,6 +2680,37 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     gx = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
     dim3 grid((unsigned)gx, (unsigned)nblk_n, (unsigned)x->B);
     if (stats) { q.stats = stats; *stats_chunks = 1; }
+    if constexpr (!F32) {
+      // two 4-wave groups per CU alternating matrix and staging phases (conv_mfma_duo_k): full 32-channel output tiles with
+      // 16-byte stores, 16-channel input chunks
+      // Measured (128^3, batch 2): 32 -> 32 forward 282-315 us against 321-339 us on conv_mfma_halo2_k, but 64 -> 32 732-757
+      // against 683-704 and 128 -> 64 at 64^3 315 against 291: with more than two 16-channel chunks the weight images are
+      // refetched every step, in 32-byte pieces of 128-byte rows, and the staging group becomes the longer half of a phase.
+      // So: the C == 32 layers only (COMA_DUO_ALL=1: every thick layer, COMA_NO_DUO=1: none).
+      static const bool no_duo = getenv("COMA_NO_DUO") != nullptr, duo_all = getenv("COMA_DUO_ALL") != nullptr;
+      if (!no_duo && !thin && vec && (q.C == 32 || (duo_all && q.C >= 32 && q.C % 16 == 0)) && q.N % 32 == 0 && q.st16 &&
+          q.D <= 510 && q.H <= 510 && q.W <= 510) {
+        int g2 = 256 / (nblk_n * x->B);                   // one 512-thread block per CU, once
+        if (g2 < 1) g2 = 1;
+        if (g2 > q.ids_total) g2 = q.ids_total;
+        q.ids_per_block = (q.ids_total + g2 - 1) / g2;
+        g2 = (q.ids_total + q.ids_per_block - 1) / q.ids_per_block;
+        const dim3 grid2((unsigned)g2, (unsigned)nblk_n, (unsigned)x->B);
+        if (stats) { q.stats = stats; *stats_chunks = 1; }
+        const size_t lds2 = (size_t)2 * 34 * 6 * 4 * 48 + (size_t)2 * 27 * 64 * 16 + 128;
+        static bool attr2 = false;
+        if (!attr2) {
+          (void)hipFuncSetAttribute((const void*)conv_mfma_duo_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute((const void*)conv_mfma_duo_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr2 = true;
+        }
+        coma_set_kernel_tag("conv_mfma_duo_k<%d>", stats ? 1 : 0);
+        if (stats) hipLaunchKernelGGL((conv_mfma_duo_k<1>), grid2, dim3(512), lds2, s, q);
+        else hipLaunchKernelGGL((conv_mfma_duo_k<0>), grid2, dim3(512), lds2, s, q);
+        COMA_LAUNCH_CHECK();
+        return 0;
+      }
+    }
     constexpr int HV2 = 34 * 6 * 4;
     const bool resident = thin || (!F32 && q.C == 32);
     // C >= 64: all 27 taps of the current 32-channel chunk in LDS, refetched per chunk (RESIDENT = 2).  The 9-taps-per-

@@ -914,10 +914,54 @@ def test_tconv_halo_kernel_stats_and_accumulate(dims, dtype):
     assert rel(to_ext(y2), want) < 2 * tol, rel(to_ext(y2), want)
 
 
+@pytest.mark.parametrize("case", [
+    # cin, cout, dims, what: the two-group kernel's corner cases -- partial tiles on every axis, one tile only (a group with
+    # nothing to do), an odd number of tiles per block, two 32-channel output tiles, the data-gradient (flipped taps) form
+    (32, 32, (4, 8, 32), "fwd"), (32, 32, (5, 7, 45), "fwd"), (32, 64, (2, 4, 32), "fwd"), (32, 32, (6, 12, 96), "fwd"),
+    (64, 32, (5, 9, 40), "dgrad"), (32, 32, (3, 5, 33), "dgrad"),
+])
+def test_duo_kernel_matches_fp64_reference(case):
+    """conv_mfma_duo_k (two 4-wave groups per CU alternating matrix and staging phases; the C == 32 stride-1 layers):
+    per-sample weights + bias + fused InstanceNorm statistics against fp64 F.conv3d, with the kernel that ran asserted."""
+    ops, L = _ops()
+    lib = L.lib
+    cin, cout, dims, what = case
+    B, E = 2, 3
+    g = torch.Generator().manual_seed(cin + cout + sum(dims))
+    q = lambda t: t.bfloat16().double()
+    master = torch.randn((E, cout, cin, 3, 3, 3), generator=g) * 0.1
+    r = torch.rand((B, E), generator=g)
+    wmix = torch.einsum("be,e...->b...", r.double(), master.double()).float().bfloat16().double()
+    if what == "fwd":
+        x = q(torch.randn((B, cin, *dims), generator=g))
+        bias = torch.randn((B, cout), generator=g)
+        yr = torch.cat([F.conv3d(x[i:i + 1], wmix[i], bias[i].double(), padding=1) for i in range(B)], 0)
+        wk_f, _ = ops.PrepWeights.apply(master.cuda(), r.cuda(), False, torch.bfloat16, None)
+        y, sums = ops._conv_fwd(to_int(x).to("cuda", torch.bfloat16), wk_f, bias.cuda(), 3, 1, 0, True, 2, None, L.NORM_INSTANCE)
+        tag = lib.coma_last_kernel().decode()
+        assert tag == "conv_mfma_duo_k<1>", tag
+        assert torch.isfinite(y.float()).all() and rel(to_ext(y), yr) < 5e-3, rel(to_ext(y), yr)
+        mean, rstd = ops.stats_from_sums(sums, B, cout, dims[0] * dims[1] * dims[2], 1e-5)
+        yf = y.double()
+        m_ref, v_ref = yf.mean((1, 2, 3)), yf.var((1, 2, 3), unbiased=False)
+        assert float((mean.double() - m_ref).abs().max()) < 1e-5 * (1.0 + float(m_ref.abs().max()))
+        assert rel(rstd.double(), (v_ref + 1e-5).rsqrt()) < 1e-5
+    else:
+        # data gradient of a cin -> cout layer: dy has cout channels... the kernel's input is dy (C = cout = 32)
+        dy = q(torch.randn((B, cout, *dims), generator=g))
+        dxr = torch.cat([F.conv_transpose3d(dy[i:i + 1], wmix[i], None, padding=1) for i in range(B)], 0)
+        _, wk_d = ops.PrepWeights.apply(master.cuda(), r.cuda(), False, torch.bfloat16, torch.bfloat16)
+        xi = torch.empty((B, *dims, cin), dtype=torch.bfloat16, device="cuda")
+        dx, _, _ = ops._conv_bwd(xi, wk_d, to_int(dy).to("cuda", torch.bfloat16), 3, 1, 0, True, 2, (B, 27, cout, cin), True, False, 0, None)
+        tag = lib.coma_last_kernel().decode()
+        assert tag == "conv_mfma_duo_k<0>", tag
+        assert torch.isfinite(dx.float()).all() and rel(to_ext(dx), dxr) < 5e-3, rel(to_ext(dx), dxr)
+
+
 DISPATCH_ROWS = [
     # cin, cout, k, stride, transposed, coarse/in dims, dtype -> kernel that must run forward / data gradient / weight gradient
-    (32, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_halo2_k<1, 32", "conv_mfma_halo2_k<1, 32", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
-    (64, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_halo2_k<2, 32", "conv_mfma_halo2_k<1, 32", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
+    (32, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_duo_k<0>", "conv_mfma_duo_k<0>", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
+    (64, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_halo2_k<2, 32", "conv_mfma_duo_k<0>", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
     (64, 32, 3, 2, True, (3, 4, 33), torch.bfloat16, "conv_mfma_tconv_k<__bf16", "conv_mfma_gather_k<64, 0, __bf16>", "conv_bf16_wgrad16_k<2, 1>"),
     (32, 64, 3, 2, False, (6, 8, 66), torch.bfloat16, "conv_mfma_gather_k<64, 0, __bf16>", "conv_mfma_tconv_k<__bf16, 0>", "conv_bf16_wgrad16_k<2, 0>"),
     (64, 32, 3, 2, True, (3, 4, 33), torch.float32, "conv_mfma_tconv_k<float", "conv_mfma_gather_k<64, 0, float>", "conv_f32_wgrad16_k<2, 1>"),
