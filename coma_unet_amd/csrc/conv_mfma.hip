@@ -2225,23 +2225,22 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
   }
   const int w_base = fr * P + fh * 16;
 
-  uint4 hreg[HIT], wreg[WIT];
+  typedef unsigned tc_u32x4_t __attribute__((ext_vector_type(4)));      // (native vectors: see conv_mfma_duo_k)
+  tc_u32x4_t hreg[HIT], wreg[WIT];
   // lim: the tile's packed limits ((D - z0 - 1) << 20 | (H - y0 - 1) << 10 | (W - x0 - 1)) | GUARD, fields clamped to 511
   auto tile_lim = [&](int z0, int y0, int x0) -> unsigned {
     const int lz = p.D - z0 - 1 < 511 ? p.D - z0 - 1 : 511, ly = p.H - y0 - 1 < 511 ? p.H - y0 - 1 : 511, lx = p.W - x0 - 1 < 511 ? p.W - x0 - 1 : 511;
     return ((unsigned)lz << 20) | ((unsigned)ly << 10) | (unsigned)lx | GUARD;
   };
-  auto halo_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int it, unsigned lim, unsigned org_b) -> uint4 {
+  auto halo_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int it, unsigned lim, unsigned org_b) -> tc_u32x4_t {
     const bool ok = ((lim - h_zyx[it]) & GUARD) == GUARD;
     const unsigned voff = ok ? org_b + h_boff[it] : OOB;
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-    return make_uint4(v[0], v[1], v[2], v[3]);
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
   };
   // slot 2 it + w_s0 of pass `grp` holds tap TC_TAP[grp][slot] (27 = the empty 14th slot of group A: reads as zero)
-  auto w_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int it, int grp, int c0_b) -> uint4 {
+  auto w_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int it, int grp, int c0_b) -> tc_u32x4_t {
     const unsigned voff = grp ? w_off[1][it] : w_off[0][it];
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, c0_b, 0);
-    return make_uint4(v[0], v[1], v[2], v[3]);
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, c0_b, 0);
   };
   auto tile_org = [&](int z0, int y0, int x0, int c0) -> unsigned {
     return (unsigned)((((long)(z0 * p.H + y0) * p.W + x0) * p.ldx + c0) * (long)sizeof(T));
@@ -2289,9 +2288,9 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
         __syncthreads();                       // all waves finished reading the previous halo / weights
 #pragma unroll
         for (int it = 0; it < HIT; ++it)
-          if (tid + 256 * it < HP) *reinterpret_cast<uint4*>(Hl + h_lds[it]) = hreg[it];
+          if (tid + 256 * it < HP) *reinterpret_cast<tc_u32x4_t*>(Hl + h_lds[it]) = hreg[it];
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) *reinterpret_cast<uint4*>(Wl + w_lds0 + it * W_LSTEP) = wreg[it];
+        for (int it = 0; it < WIT; ++it) *reinterpret_cast<tc_u32x4_t*>(Wl + w_lds0 + it * W_LSTEP) = wreg[it];
         __syncthreads();
         // what to prefetch while this step computes: the next chunk of this pass, chunk 0 of the tile's second pass, or
         // chunk 0 / pass A of the next tile; through descriptors whose range is zero when there is nothing left (no branch)

@@ -13,15 +13,22 @@ echo "== pmc write"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_wr
 echo "== kernel trace fp32"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fp32 -o t -- $B --dtype fp32 > $O/r03_bench_fp32_under_rocprof.json 2> $O/prof_fp32.err
 cd $GRAFT_REPO_ROOT
 python profiles/trace_summary.py $(find $O/prof_bf16 -name '*kernel_trace.csv' | head -1) 9 > $O/r03_bf16_kernel_trace_summary.txt
+python profiles/overlap_timeline.py $(find $O/prof_bf16 -name '*kernel_trace.csv' | head -1) > $O/r03_bf16_overlap_timeline.txt || true
 cp $(find $O/prof_bf16 -name '*kernel_stats.csv' | head -1) $O/r03_bf16_kernel_stats.csv
 python profiles/trace_summary.py $(find $O/prof_fp32 -name '*kernel_trace.csv' | head -1) 9 > $O/r03_fp32_kernel_trace_summary.txt
 cp $(find $O/prof_fp32 -name '*kernel_stats.csv' | head -1) $O/r03_fp32_kernel_stats.csv
 python profiles/pmc_summary.py $O/pmc_fetch $O/pmc_write --traffic-json $O/r03_pmc_traffic.json > $O/r03_pmc_bf16_fetch_write.txt
 rm -rf $O/prof_bf16 $O/prof_fp32 $O/pmc_fetch $O/pmc_write
 head -12 $O/r03_bf16_kernel_trace_summary.txt
+echo "== side-stream picture"
+python profiles/side_stamps.py > $O/r03_side_stamps.txt 2>&1 || true
+tail -3 $O/r03_side_stamps.txt
+bash profiles/ab_env.sh "COMA_WGRAD_SIDE=0" "COMA_NO_DUO=1" > $O/r03_ab_side_duo.txt 2>&1 || true
+cat $O/r03_ab_side_duo.txt
 echo "== microbenchmarks"
 python profiles/microbench_norm.py > $O/r03_microbench_norm.txt 2>&1 || true
 bash profiles/mb_tconv.sh > $O/r03_microbench_tconv.txt 2>&1 || true
+OTHER= bash profiles/mb_halo2.sh > $O/r03_microbench_thick.txt 2>&1 || true
 python profiles/microbench_wprep.py > $O/r03_microbench_wprep.txt 2>&1 || true
 echo "== data-parallel rehearsal (gloo, 2 ranks on one GPU, 32^3)"
 for mode in torch capi capi-sharded; do
