@@ -542,6 +542,8 @@ struct Halo2P {
   int st16;            // ... and aligned 16-byte (8-channel) stores
   double2* stats;      // optional: per-block {sum, sumsq} of the stored outputs, [chunk][G][N]
   int stats_inst;      // B: groups = the B samples (InstanceNorm), 0: one group (BatchNorm)
+  const void* wfrag;   // conv_mfma_duo_k, C >= 64: the weights re-laid in fragment order (duo_relayout_k), else null
+  long wfrag_sb;       // ... elements between two samples' weight sets
 };
 
 // CK = channels per LDS row (bf16: 32, or 16 for the thin full-resolution layers: one MFMA K step per tap; fp32: 16);
@@ -1067,6 +1069,22 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_halo2_k(Halo2P p) {
 //   A wave's two M-tiles are y-neighbours: for a fixed (kz, kx) their three ky taps read four distinct halo rows, so a
 //   (kz, kx) group is 4 + 3 fragment reads for 6 MFMAs.
 // =====================================================================================
+// wk[b][tap][N][C] -> [b][n tile][16-channel chunk][tap][lane = (n & 31) + 32 * ((c >> 3) & 1)][8 channels]: the order in which
+// conv_mfma_duo_k holds a weight image in LDS, so that a group's half image is ONE contiguous 13.8 KB run (from the plain
+// layout a 16-channel piece is 32 bytes of a 2 C-byte row: at C = 64 the staging group pulled 4x the useful bytes through L1)
+__global__ __launch_bounds__(256) void duo_relayout_k(const uint4* __restrict__ src, uint4* __restrict__ dst, int N, int C8, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;      // piece (b, tap, n, c8)
+  if (i >= total) return;
+  const int c8 = (int)(i % C8);
+  long t = i / C8;
+  const int n = (int)(t % N); t /= N;
+  const int tap = (int)(t % 27);
+  const long b = t / 27;
+  const int nt = N >> 5, nch = C8 >> 1;
+  const long o = ((((b * nt + (n >> 5)) * nch + (c8 >> 1)) * 27 + tap) * 64) + (n & 31) + 32 * (c8 & 1);
+  dst[o] = src[i];
+}
+
 __device__ __forceinline__ void duo_barrier() {
   // LDS traffic of this wave has landed; buffer loads issued for later phases stay in flight (no vmcnt wait)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1111,10 +1129,13 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
   // constant -- its global offset is rebuilt at every fetch (a handful of VALU on the staging wave; registers are the
   // scarce thing at two waves per SIMD)
   const int w_q0 = w_half + gt;
-  const unsigned w_lane_b = (unsigned)((((n0 + (w_q0 & 31)) * p.C) + ((w_q0 >> 5) & 1) * 8) * 2);
+  const bool wf = p.wfrag != nullptr;                         // fragment-ordered weights: piece q of a chunk image sits at q * 16
+  const unsigned w_lane_b = wf ? (unsigned)((w_q0 & 63) * 16)
+                               : (unsigned)((((n0 + (w_q0 & 31)) * p.C) + ((w_q0 >> 5) & 1) * 8) * 2);
   const int w_lds0 = w_q0 * 16;                               // + it * 4096
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xb), 0, p.xbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wb), 0, p.wbytes, 0x00020000);
+  const bf16_t* wfb = wf ? static_cast<const bf16_t*>(p.wfrag) + (long)b * p.wfrag_sb + (long)blockIdx.y * (nch * 27 * 512) : wb;
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wfb), 0, wf ? (unsigned)(nch * 27 * 1024) : p.wbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xb), 0, 0, 0x00020000);   // reads as zero
 
   // fragment bases: this wave's M-tiles are rows y0, y0 + 1 of plane zq
@@ -1175,9 +1196,9 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
       if (gt + 256 * it < HP) *reinterpret_cast<u32x4_t*>(Hl + h_lds0 + it * 128 * P) = hreg[it];
   };
   auto load_w = [&](int ws, bool on) {               // this group's half of weight step ws (chunk ws % nch)
-    const int c0_b = (ws % nch) * 32;
+    const int c0_b = wf ? (ws % nch) * (27 * 1024) : (ws % nch) * 32;
     const __amdgpu_buffer_rsrc_t rs = on ? rs_w : rs_0;
-    const unsigned tap_b = (unsigned)(p.N * p.C * 2);
+    const unsigned tap_b = wf ? 1024u : (unsigned)(p.N * p.C * 2);
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
       const int tap = (w_q0 >> 6) + 4 * it;
@@ -2605,12 +2626,21 @@ static int launch_halo(const HaloP& p0, int B, hipStream_t s) {
   return 0;
 }
 
+// bytes of scratch conv_mfma_duo_k wants for a fragment-ordered copy of the weights (C >= 64 stride-1 3^3 bf16 layers), else 0
+static bool aligned16(const void* p);
+static size_t duo_frag_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
+  static const bool on = getenv("COMA_DUO_C32_ONLY") == nullptr && getenv("COMA_NO_DUO") == nullptr;
+  if (!on || x->dtype != COMA_BF16 || d->ksize != 3 || d->stride != 1 || x->W < 32) return 0;
+  if (x->C < 64 || x->C % 16 || y->C % 32) return 0;
+  return (size_t)(d->per_sample_w ? x->B : 1) * 27 * y->C * x->C * 2;
+}
+
 // stats != NULL requests fused {sum, sumsq} partials; *stats_chunks receives the number of chunks written, or stays
 // 0 when the selected kernel variant cannot fuse them (the caller then runs the stand-alone statistics pass).
 template <typename T>
 static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const void* wk, const float* bias,
                           const coma_tensor* y, hipStream_t s, double2* stats = nullptr, int stats_inst = 0,
-                          int* stats_chunks = nullptr) {
+                          int* stats_chunks = nullptr, void* ws = nullptr, size_t ws_bytes = 0) {
   constexpr int EPB = elem<T>::EPB;
   constexpr bool F32 = EPB == 4;
   HaloP p;
@@ -2682,13 +2712,24 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     if constexpr (!F32) {
       // two 4-wave groups per CU alternating matrix and staging phases (conv_mfma_duo_k): full 32-channel output tiles with
       // 16-byte stores, 16-channel input chunks
-      // Measured (128^3, batch 2): 32 -> 32 forward 282-315 us against 321-339 us on conv_mfma_halo2_k, but 64 -> 32 732-757
-      // against 683-704 and 128 -> 64 at 64^3 315 against 291: with more than two 16-channel chunks the weight images are
-      // refetched every step, in 32-byte pieces of 128-byte rows, and the staging group becomes the longer half of a phase.
-      // So: the C == 32 layers only (COMA_DUO_ALL=1: every thick layer, COMA_NO_DUO=1: none).
-      static const bool no_duo = getenv("COMA_NO_DUO") != nullptr, duo_all = getenv("COMA_DUO_ALL") != nullptr;
-      if (!no_duo && !thin && vec && (q.C == 32 || (duo_all && q.C >= 32 && q.C % 16 == 0)) && q.N % 32 == 0 && q.st16 &&
+      // Measured (128^3, batch 2; microbenchmarks, duo / halo2): 32 -> 32 forward 282-315 / 321-339 us.  C >= 64 from the plain
+      // weight layout was SLOWER (64 -> 32 732-757 / 683-704 us: a 16-channel weight piece is 32 bytes of a 128-byte row and the
+      // staging group pulled 4x the useful bytes through L1); with the weights re-laid in fragment order by a 4-us launch
+      // (duo_relayout_k into the caller's scratch, coma_conv_fwd_ws_bytes): 64 -> 32 696 / 691 and 665 / 689 (data gradient),
+      // 64 -> 64 at 64^3 129 / 144 and 134 / 150, 128 -> 64 270 / 273 and 277 / 297, 256 -> 128 at 32^3 117 / 125 and 126 / 134;
+      // step 18.09 -> 17.99 ms.  COMA_NO_DUO=1: conv_mfma_halo2_k everywhere; COMA_DUO_C32_ONLY=1: the C == 32 layers only.
+      static const bool no_duo = getenv("COMA_NO_DUO") != nullptr, duo_all = getenv("COMA_DUO_C32_ONLY") == nullptr;
+      q.wfrag = nullptr; q.wfrag_sb = 0;
+      const size_t frag_bytes = duo_frag_bytes(d, x, y);      // C >= 64: scratch for the fragment-ordered copy of the weights
+      const bool wide_ok = duo_all && q.C > 32 && frag_bytes > 0 && ws && ws_bytes >= frag_bytes && aligned16(ws);
+      if (!no_duo && !thin && vec && (q.C == 32 || wide_ok) && q.N % 32 == 0 && q.st16 &&
           q.D <= 510 && q.H <= 510 && q.W <= 510) {
+        if (q.C > 32) {
+          const long pieces = (long)(frag_bytes / 16);
+          hipLaunchKernelGGL(duo_relayout_k, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, (const uint4*)wk, (uint4*)ws, q.N, q.C / 8, pieces);
+          COMA_LAUNCH_CHECK();
+          q.wfrag = ws; q.wfrag_sb = d->per_sample_w ? 27L * q.N * q.C : 0;
+        }
         int g2 = 256 / (nblk_n * x->B);                   // one 512-thread block per CU, once
         if (g2 < 1) g2 = 1;
         if (g2 > q.ids_total) g2 = q.ids_total;
@@ -2771,7 +2812,8 @@ bool conv_mfma_accumulate_ok(const coma_conv_desc* d, const coma_tensor* x, cons
 static int gather_ksplit(long blocks, int nsteps, bool f32);
 size_t conv_mfma_fwd_ws_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   if (x->dtype == COMA_F32) { if (thin16f_ok(d, x, y) || f32_halo_ok(d, x, y)) return 0; }
-  else if (halo_ok(d, x, y) || pw_ok(d, x, y)) return 0;
+  else if (halo_ok(d, x, y)) return duo_frag_bytes(d, x, y);
+  else if (pw_ok(d, x, y)) return 0;
   if (tconv_ok(d, x, y)) return 0;
   const size_t bytes = sizeof(float) * (size_t)y->B * t_vox(y) * y->C;
   if (bytes > ((size_t)64 << 20)) return 0;
@@ -2793,7 +2835,7 @@ int conv_mfma_fwd(const coma_conv_desc* d, const coma_tensor* x, const void* wk,
   COMA_CHECK(!accum || conv_mfma_accumulate_ok(d, x, y), "conv_mfma: this problem's kernel family cannot accumulate into y");
   if (f32 && thin16f_ok(d, x, y)) return conv_thin16f(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
   if (f32) { if (f32_halo_ok(d, x, y)) return conv_mfma_halo<float>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks); }
-  else if (halo_ok(d, x, y)) return conv_mfma_halo<bf16_t>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks);
+  else if (halo_ok(d, x, y)) return conv_mfma_halo<bf16_t>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks, ws, ws_bytes);
   if (tconv_ok(d, x, y)) {
     if (f32) return conv_mfma_tconv<float>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks, accum);
     return conv_mfma_tconv<bf16_t>(d, x, wk, bias, y, s, stats, stats_inst, stats_chunks, accum);

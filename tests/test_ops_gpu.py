@@ -919,9 +919,11 @@ def test_tconv_halo_kernel_stats_and_accumulate(dims, dtype):
     # nothing to do), an odd number of tiles per block, two 32-channel output tiles, the data-gradient (flipped taps) form
     (32, 32, (4, 8, 32), "fwd"), (32, 32, (5, 7, 45), "fwd"), (32, 64, (2, 4, 32), "fwd"), (32, 32, (6, 12, 96), "fwd"),
     (64, 32, (5, 9, 40), "dgrad"), (32, 32, (3, 5, 33), "dgrad"),
+    # more than two 16-channel chunks: the weights go through the fragment-order re-layout (duo_relayout_k) and are refetched per step
+    (64, 32, (5, 7, 45), "fwd"), (128, 64, (4, 8, 32), "fwd"), (32, 64, (3, 5, 40), "dgrad"), (64, 128, (2, 8, 64), "dgrad"),
 ])
 def test_duo_kernel_matches_fp64_reference(case):
-    """conv_mfma_duo_k (two 4-wave groups per CU alternating matrix and staging phases; the C == 32 stride-1 layers):
+    """conv_mfma_duo_k (two 4-wave groups per CU alternating matrix and staging phases; the thick stride-1 layers):
     per-sample weights + bias + fused InstanceNorm statistics against fp64 F.conv3d, with the kernel that ran asserted."""
     ops, L = _ops()
     lib = L.lib
@@ -961,7 +963,7 @@ def test_duo_kernel_matches_fp64_reference(case):
 DISPATCH_ROWS = [
     # cin, cout, k, stride, transposed, coarse/in dims, dtype -> kernel that must run forward / data gradient / weight gradient
     (32, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_duo_k<0>", "conv_mfma_duo_k<0>", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
-    (64, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_halo2_k<2, 32", "conv_mfma_duo_k<0>", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
+    (64, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_duo_k<0>", "conv_mfma_duo_k<0>", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
     (64, 32, 3, 2, True, (3, 4, 33), torch.bfloat16, "conv_mfma_tconv_k<__bf16", "conv_mfma_gather_k<64, 0, __bf16>", "conv_bf16_wgrad16_k<2, 1>"),
     (32, 64, 3, 2, False, (6, 8, 66), torch.bfloat16, "conv_mfma_gather_k<64, 0, __bf16>", "conv_mfma_tconv_k<__bf16, 0>", "conv_bf16_wgrad16_k<2, 0>"),
     (64, 32, 3, 2, True, (3, 4, 33), torch.float32, "conv_mfma_tconv_k<float", "conv_mfma_gather_k<64, 0, float>", "conv_f32_wgrad16_k<2, 1>"),
