@@ -1111,14 +1111,11 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
   const bool w_static = nch <= 2;
 
   // ---- staging descriptors ----
-  unsigned h_roff[HIT], h_zyx[HIT];
-#pragma unroll
-  for (int it = 0; it < HIT; ++it) {
-    const int piece = gt + 256 * it, row = piece >> 1, half = piece & 1;
-    const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
-    h_zyx[it] = piece < HP ? ((unsigned)hz << 20) | ((unsigned)hy << 10) | (unsigned)hx : 0x1ff7fdffu;      // (invalid: above any limit)
-    h_roff[it] = (unsigned)((((hz * p.H + hy) * p.W + hx) * p.ldx + half * 8) * 2);
-  }
+  // Halo piece `it` of this thread is row (gt >> 1) + 128 it, half gt & 1.  Its halo coordinates and global offset are
+  // rebuilt from the FIRST piece's coordinates at every fetch (row + 128 = 3 x-lines + 26: a few adds and compares per
+  // piece on the staging wave) instead of living in 14 registers: at two waves per SIMD registers are the scarce thing.
+  const int h_row0 = gt >> 1, h_half = gt & 1;
+  unsigned h_zyx0 = ((unsigned)(h_row0 / (HX * HY)) << 20) | ((unsigned)((h_row0 / HX) % HY) << 10) | (unsigned)(h_row0 % HX);
   // in-volume test of a halo piece as two packed subtractions (fields of 9 bits under a guard bit each): halo coordinate h
   // of a tile at origin o is inside iff lo <= h <= hi with lo = (o == 0), hi = min(dim - o, 510) per axis
   constexpr unsigned GUARD = (1u << 29) | (1u << 19) | (1u << 9);
@@ -1169,13 +1166,17 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
   }
   const int nsteps = (nt0 > nt1 ? nt0 : nt1) * nch;
   if (nsteps == 0) return;
-  const int nphases = 2 * nsteps + 2;                // + 1 round: group 1's last tile is finished in a staging phase
+  const int nphases = 2 * nsteps + 4;                // (a multiple of 4: nch is even) + 1 round: the last tiles are finished in a staging phase
 
   // (native 4-dword vectors: as HIP uint4 structs the loop-carried pieces were split into scalars, the loads landed in
   // temporaries and the copies into the carried registers put an s_waitcnt vmcnt(0) in front of every barrier)
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  u32x4_t hreg[HIT], wreg[WIT];
-  auto load_halo = [&](const Cur& c) {
+  // Halo pieces are fetched for TWO consecutive chunk steps at once (hreg[0]: the even chunk, hreg[1]: the odd one -- the
+  // two 32-byte halves of a 64-byte run of every voxel row) and written to LDS one step apart: fetched one step at a time,
+  // every 128-byte line went through L1 once per 16-channel chunk (4x the useful bytes at C = 64; staging alone 506 us
+  // for 64 -> 32 at 128^3 next to 325 us of matrix phases).
+  u32x4_t hreg[2][HIT], wreg[WIT];
+  auto load_halo = [&](const Cur& c) {               // c: the even chunk step of a pair
     const int z0 = c.tiz * TZ, y0 = c.tiy * TY, x0 = c.tix * TX;
     const int zb = z0 - 1, yb0 = y0 - 1, xb0 = x0 - 1;
     const unsigned org_b = (unsigned)((((long)(zb * p.H + yb0) * p.W + xb0) * p.ldx + c.cc * 16) * 2);
@@ -1183,18 +1184,29 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
     const unsigned lo = ((unsigned)(z0 == 0) << 20) | ((unsigned)(y0 == 0) << 10) | (unsigned)(x0 == 0);
     const int hz_ = p.D - z0 < 510 ? p.D - z0 : 510, hy_ = p.H - y0 < 510 ? p.H - y0 : 510, hx_ = p.W - x0 < 510 ? p.W - x0 : 510;
     const unsigned hi = (((unsigned)hz_ << 20) | ((unsigned)hy_ << 10) | (unsigned)hx_) | GUARD;
+    asm volatile("" : "+v"(h_zyx0));                 // (keeps the per-piece values out of loop-invariant registers)
+    int hz = (int)(h_zyx0 >> 20), hy = (int)((h_zyx0 >> 10) & 1023), hx = (int)(h_zyx0 & 1023);
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
-      const bool ok = ((((h_zyx[it] | GUARD) - lo) & (hi - h_zyx[it])) & GUARD) == GUARD;
-      const unsigned voff = ok ? org_b + h_roff[it] : OOB;
-      hreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+      const unsigned zyx = (gt + 256 * it < HP) ? ((unsigned)hz << 20) | ((unsigned)hy << 10) | (unsigned)hx : 0x1ff7fdffu;   // (invalid: above any limit)
+      const bool ok = ((((zyx | GUARD) - lo) & (hi - zyx)) & GUARD) == GUARD;
+      const unsigned roff = (unsigned)((((hz * p.H + hy) * p.W + hx) * p.ldx + h_half * 8) * 2);
+      const unsigned voff = ok ? org_b + roff : OOB;
+      hx += 26; hy += 3;                               // the next piece: 128 rows = 3 x-lines + 26 voxels on
+      if (hx >= HX) { hx -= HX; ++hy; }
+      if (hy >= HY) { hy -= HY; ++hz; }
+      hreg[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+      hreg[1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 32u, 0, 0);  // (OOB + 32 is still out of range)
     }
   };
-  auto store_halo = [&]() {
+  auto store_halo = [&](auto odd_c) {
+    constexpr int odd = decltype(odd_c)::value;
 #pragma unroll
     for (int it = 0; it < HIT; ++it)
-      if (gt + 256 * it < HP) *reinterpret_cast<u32x4_t*>(Hl + h_lds0 + it * 128 * P) = hreg[it];
+      if (gt + 256 * it < HP) *reinterpret_cast<u32x4_t*>(Hl + h_lds0 + it * 128 * P) = hreg[odd][it];
   };
+  typedef std::integral_constant<int, 0> even_t;
+  typedef std::integral_constant<int, 1> odd_t;
   auto load_w = [&](int ws, bool on) {               // this group's half of weight step ws (chunk ws % nch)
     const int c0_b = wf ? (ws % nch) * (27 * 1024) : (ws % nch) * 32;
     const __amdgpu_buffer_rsrc_t rs = on ? rs_w : rs_0;
@@ -1229,17 +1241,21 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
   if (tid < 32) bias_l[tid] = p.bias ? p.bias[b * p.bsb + n0 + tid] : 0.f;
 
   // ---- prologue: weight step 0 complete, group 0's first halo in place, the next loads in flight ----
-  Cur cC, cB, cA;            // computed last / fetched (to be stored next) / to fetch next
+  Cur cC, cB, cA;            // computed last / to be stored next / the next PAIR of chunk steps to fetch (cA.cc even)
   cC.valid = 0; cC.cc = 0; cC.tix = cC.tiy = cC.tiz = 0; cC.id = 0;
   first_tile(cB, id_begin + grp);
-  cA = cB; advance(cA);
-  load_halo(cB);
+  cA = cB;
+  auto advance2 = [&](Cur& c) {                      // two chunk steps on (nch is even)
+    if (!c.valid) return;
+    if (c.cc + 2 < nch) { c.cc += 2; return; }
+    first_tile(c, c.id + 2);
+  };
+  load_halo(cA); advance2(cA);                       // steps 0 and 1
   load_w(0, true);
   store_w(0);
   if (grp == 0) {
-    store_halo();
-    cC = cB; cB = cA; advance(cA);
-    load_halo(cB);
+    store_halo(even_t{});
+    cC = cB; advance(cB);
   }
   load_w(1, w_needed(1));
   duo_barrier();
@@ -1285,16 +1301,20 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
       }
   };
   // ================= everything else, for this group's NEXT matrix phase =================
-  auto other_phase = [&](int ph) __attribute__((always_inline)) {
+  // (two forms, chosen at compile time: EVEN writes the even chunk step of a pair and finishes the tile the previous odd step
+  // completed; ODD writes the odd step and fetches the next pair -- a run-time choice put the fetch behind a branch, and
+  // loop-carried pieces behind a branch are copied through temporaries with a vmcnt(0) wait)
+  auto other_phase = [&](auto odd_c, int ph) __attribute__((always_inline)) {
+      constexpr int odd = decltype(odd_c)::value;
 #ifdef COMA_DUO_NO_STAGE
       if (cC.valid && cC.cc == nch - 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(acc[i]));
       }
-      cC = cB; cB = cA; advance(cA);
+      cC = cB; advance(cB);
       return;
 #endif
-      store_halo();                                     // (waits for the pieces fetched two phases ago)
+      store_halo(odd_c);                                // (waits for the pieces fetched two or more phases ago)
       const int ws = (ph >> 1) + 1;
       if (w_needed(ws)) store_w(ws);
       // every piece fetched two phases ago has been consumed (or, masked off, may be dropped): say so -- a piece stored under
@@ -1302,6 +1322,7 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
       // the next fetch AND at the start of the next matrix phase
       __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): free at run time, the pieces are two phases old
       // finish the tile whose last chunk this group computed in the previous phase
+      if constexpr (odd == 0) {
 #ifdef COMA_DUO_NO_EPI
       if (cC.valid && cC.cc == nch - 1) {          // (diagnostic: the accumulators stay live, nothing is stored)
 #pragma unroll
@@ -1345,9 +1366,10 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
         }
       }
 #endif
-      // rotate the walk and fetch the step after next
-      cC = cB; cB = cA; advance(cA);
-      load_halo(cB);
+      }
+      // rotate the walk; behind the odd step of a pair, fetch the next pair
+      cC = cB; advance(cB);
+      if constexpr (odd == 1) { load_halo(cA); advance2(cA); }
       if (w_needed(ws + 1)) load_w(ws + 1, true);
   };
   // Two straight-line loops, one per role order (NOT one loop with a role branch: the pieces in flight are loop-carried
@@ -1357,12 +1379,18 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
   // loop's) into the loop header state and then waits vmcnt(0) wherever the loop body reuses one of those registers --
   // at the start of every matrix phase.  (The builtin, not inline asm: the pass has to see this wait.)
   __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only
-  if (grp == 0) {
+  if (grp == 0) {        // (its first halo was written by the prologue: even step in place, the odd one follows)
 #pragma unroll 1
-    for (int ph = 0; ph < nphases; ph += 2) { matrix_phase(ph); duo_barrier(); other_phase(ph + 1); duo_barrier(); }
+    for (int ph = 0; ph < nphases; ph += 4) {
+      matrix_phase(ph); duo_barrier(); other_phase(odd_t{}, ph + 1); duo_barrier();
+      matrix_phase(ph + 2); duo_barrier(); other_phase(even_t{}, ph + 3); duo_barrier();
+    }
   } else {
 #pragma unroll 1
-    for (int ph = 0; ph < nphases; ph += 2) { other_phase(ph); duo_barrier(); matrix_phase(ph + 1); duo_barrier(); }
+    for (int ph = 0; ph < nphases; ph += 4) {
+      other_phase(even_t{}, ph); duo_barrier(); matrix_phase(ph + 1); duo_barrier();
+      other_phase(odd_t{}, ph + 2); duo_barrier(); matrix_phase(ph + 3); duo_barrier();
+    }
   }
 
   // ---- fused statistics: lanes -> wave -> block (LDS) -> the caller's record ----
