@@ -136,6 +136,24 @@ def rooflines(byk, timer_steps, peak_tf, step_roof, timer_note):
     return roof, first("mfma"), first("hbm")
 
 
+def family_roofline(byk, timer_steps, peak_tf, prefix):
+    """One roofline entry for ALL instantiations of a kernel template (e.g. conv_mfma_duo_k<0> and <1>, the same kernel
+    without / with the fused statistics), named as the ' + '-joined list of the kernels it sums over."""
+    sel = sorted((k, v) for k, v in byk.items() if k.startswith(prefix))
+    if not sel:
+        return None
+    n = sum(v[0] for _k, v in sel); ms = sum(v[1] for _k, v in sel); fl = sum(v[2] for _k, v in sel); by = sum(v[3] for _k, v in sel)
+    name = " + ".join(k for k, _v in sel)
+    ach = fl / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4),
+            "kernel": name, "launches_per_step": n / timer_steps, "avg_launch_us": round(ms / n * 1e3, 2),
+            "ms_per_step": round(ms / timer_steps, 3), "alg_flops_per_launch": round(fl / n), "alg_bytes_per_launch": round(by / n),
+            "traffic": (lambda t: None if any(x is None for x in t) else sum(x * v[0] for x, (_k, v) in zip(t, sel)) / n)(
+                [pmc_traffic(k) for k, _v in sel]),       # launch-weighted mean of the members' PMC bytes per launch
+            "per_kernel": {k: {"launches_per_step": v[0] / timer_steps, "ms_per_step": round(v[1] / timer_steps, 3),
+                               "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sel}}
+
+
 def timed_steps(fn, steps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -401,13 +419,16 @@ def main():
         step_ach = value * unet_tf
         step_roof = {"unet_tflop_per_volume": round(unet_tf, 4), "achieved_tflops": round(step_ach, 2), "peak": peak_tf,
                      "frac": round(step_ach / peak_tf, 4)}
-        roof_mfma = roof_hbm = None
+        roof_mfma = roof_hbm = roof_thick = None
         if summ:
             for (kind, algo), (n, ms, fl, by) in sorted(summ.items()):
                 kernels[f"{kind}/{algo}"] = {"launches": n, "ms_total": round(ms, 3),
                                              "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
                                              "alg_GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
             roof, roof_mfma, roof_hbm = rooflines(byk, timer_steps, peak_tf, step_roof, timer_note)
+            # the thick stride-1 forward / data-gradient kernel is two instantiations of one template (without / with the
+            # fused statistics): reported once more as a family, next to the per-name entries above
+            roof_thick = family_roofline(byk, timer_steps, peak_tf, "conv_mfma_duo_k" if args.dtype == "bf16" else "conv_mfma_halo2_k")
         line = {
             "metric": f"volumes/sec (train fwd+bwd) at 128^3 {args.dtype}", "value": round(value, 4), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -423,7 +444,8 @@ def main():
                        "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 1)},
             "loss": round(loss, 4), "note": graph_note,
             "unet_tflops_per_s": round(step_ach, 2),
-            "roofline": roof, "roofline_mfma": roof_mfma, "roofline_hbm": roof_hbm, "conv_kernels": kernels,
+            "roofline": roof, "roofline_mfma": roof_mfma, "roofline_hbm": roof_hbm, "roofline_thick_conv": roof_thick,
+            "conv_kernels": kernels,
             "zero_arena_mb": {str(k): round(a.peak / 2 ** 20, 1) for k, a in ops.ZeroArena._arenas.items()},
             "data_parallel": dp_info,
         }
