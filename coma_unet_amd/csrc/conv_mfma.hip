@@ -1265,8 +1265,10 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
 #ifdef COMA_DUO_NO_MFMA          // (diagnostic builds only: profiles/ablate_duo.sh)
       return;
 #endif
-      if (cC.valid) {
-        if (cC.cc == 0) {          // a new tile (zeroed here, in place: zeroing in the epilogue made the compiler keep a second copy)
+      if (__builtin_amdgcn_readfirstlane(cC.valid)) {
+        // (readfirstlane: the walk's fields may live in VGPRs, and a vector compare turned this into 32 v_cndmask per phase)
+        if (__builtin_amdgcn_readfirstlane(cC.cc) == 0) {          // a new tile (zeroed here, in place: zeroing in the epilogue made the compiler keep a second copy)
+          asm volatile("" ::: "memory");       // (a real branch: if-converted, this is 32 v_cndmask in every matrix phase)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
