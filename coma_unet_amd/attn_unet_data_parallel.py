@@ -356,9 +356,18 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         cfgs = (self.cfg, self.cfg_heads) if self.training else ()
         for c in cfgs:
             c.begin_forward()
+        # every layer's routing + expert mix up front, on a few streams beside each other (ops.PrepAhead; the first forward of
+        # a configuration records which layers prepare what)
+        if covariate is not None and covariate.dim() == 3 and x.is_cuda:
+            ops.PrepAhead.begin(self, (tuple(x.shape), x.dtype, self.cfg.compute_dtype, self.training, torch.is_grad_enabled(),
+                                       bool(x.requires_grad), self.static_prompts), x.device, covariate, x.shape[0])
+        ok = False
         try:
-            return self._forward(x, xi, covariate, roi_pred_dicts, sample_roi_mask)
+            res = self._forward(x, xi, covariate, roi_pred_dicts, sample_roi_mask)
+            ok = True
+            return res
         finally:
+            ops.PrepAhead.end(ok)
             for c in cfgs:
                 c.end_forward()
 

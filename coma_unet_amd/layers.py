@@ -127,9 +127,12 @@ def conv_plain(cfg, x, conv: nn.Module, ksize, stride, transposed, out=None, nor
     n_out = conv.weight.shape[1] if transposed else conv.weight.shape[0]
     a_f, a_d = ops.pick_algo(x.shape, x.dtype, n_out, ksize, stride, transposed, False, x.device, cfg.conv_algo)
     need_dx = x.requires_grad
+    fdt, ddt = _wdtype(a_f), (_wdtype(a_d) if need_dx else None)
+    pre = ops.PrepAhead.take(conv.weight, transposed, fdt, ddt)        # prepared at the start of this forward?
+    ops.PrepAhead.note(conv.weight, None, None, transposed, fdt, ddt)
     return ops.ConvLayer.apply(x, conv.weight, None, conv.bias, ksize, stride, transposed, cfg.conv_algo,
-                               Out(out) if out is not None else None, norm, _wdtype(a_f), _wdtype(a_d) if need_dx else None,
-                               cfg.zero_bias_grad_under_norm)
+                               Out(out) if out is not None else None, norm, fdt, ddt,
+                               cfg.zero_bias_grad_under_norm, pre[2:] if pre is not None else None)
 
 
 class Convolution(nn.Module):
@@ -224,14 +227,22 @@ def conv_cond(cfg, x, cc: CondConv3d, covariate, out=None, norm=None):
         main = torch.cuda.current_stream(x.device)
         r.record_stream(main)
         bias.record_stream(main)
-    else:
-        r, bias = ops.Routing.apply(cov, cc.routing.weight, cc.routing.bias, cc.bias)    # (B, E), (B, Cout)
+        a_f, a_d = ops.pick_algo(x.shape, x.dtype, cc.out_channels, cc.kernel_size, cc.stride, cc.is_transposed, True,
+                                 x.device, cfg.conv_algo)
+        need_dx = x.requires_grad
+        return ops.ConvLayer.apply(x, cc.weight, r, bias, cc.kernel_size, cc.stride, cc.is_transposed, cfg.conv_algo,
+                                   Out(out) if out is not None else None, norm, _wdtype(a_f), _wdtype(a_d) if need_dx else None,
+                                   cfg.zero_bias_grad_under_norm)
     a_f, a_d = ops.pick_algo(x.shape, x.dtype, cc.out_channels, cc.kernel_size, cc.stride, cc.is_transposed, True,
                              x.device, cfg.conv_algo)
     need_dx = x.requires_grad
+    fdt, ddt = _wdtype(a_f), (_wdtype(a_d) if need_dx else None)
+    pre = ops.PrepAhead.take(cc.weight, cc.is_transposed, fdt, ddt)    # routing + expert mix done at the start of this forward?
+    ops.PrepAhead.note(cc.weight, (cc.routing.weight, cc.routing.bias, cc.bias), cov.shape[1], cc.is_transposed, fdt, ddt)
+    r, bias = ops.Routing.apply(cov, cc.routing.weight, cc.routing.bias, cc.bias, pre[:2] if pre is not None else None)    # (B, E), (B, Cout)
     return ops.ConvLayer.apply(x, cc.weight, r, bias, cc.kernel_size, cc.stride, cc.is_transposed, cfg.conv_algo,
-                               Out(out) if out is not None else None, norm, _wdtype(a_f), _wdtype(a_d) if need_dx else None,
-                               cfg.zero_bias_grad_under_norm)
+                               Out(out) if out is not None else None, norm, fdt, ddt,
+                               cfg.zero_bias_grad_under_norm, pre[2:] if pre is not None else None)
 
 
 class CondConvolution(nn.Module):

@@ -214,6 +214,7 @@ class GradSink:
         cls.written.clear()
         SidePrep.join()
         SidePrep._live = 0
+        PrepAhead.live = 0
         ZeroArena.begin_step()
 
     @classmethod
@@ -369,6 +370,131 @@ class SidePrep:
         return ent[1], ent[2]
 
 
+class PrepAhead:
+    """All weight preparation of a forward pass AT ITS START, on a few streams beside each other.  Routing and the expert mix
+    / re-layout of the masters depend on parameters and covariates only; in stream order they sit in front of every
+    convolution as ~80 launches of 4-20 us (0.74 ms per 128^3 step), most of them far too small to use the chip: the mixes of
+    the 20 small layers take 5-10 us each for well under a microsecond of HBM traffic.  The first forward at a given input
+    shape RECORDS which layers prepare what (`plan`); later forwards run every entry up front on `K` streams -- the chip sees
+    them together, as parallel branches of the step graph under capture -- into persistent per-entry buffers, the main
+    stream waits once, and the layers find their weights ready (`take`).  Any deviation from the recorded order, a second
+    forward while a backward still needs the buffers, or COMA_PREP_AHEAD=0 falls back to the in-line preparation.
+    (Interleaved with the convolutions instead -- ops.SidePrep -- the same work on a second stream made the step SLOWER.)"""
+    enabled = os.environ.get("COMA_PREP_AHEAD", "1") not in ("0", "")
+    # streams: measured 17.70-17.85 ms per step without, 17.89 with 1, 17.53-17.56 with 2, 17.61 with 3, 17.85 with 4, 18.2 with 8
+    K = int(os.environ.get("COMA_PREP_AHEAD_STREAMS", "2"))
+    _streams = {}
+    _cur = None        # the running forward: {"mode", "plan", "i", "res", "owner", "key"}
+    live = 0           # ConvLayer nodes whose backward still reads the persistent buffers
+    used = 0           # layers served from the up-front preparation so far (diagnostic / tests)
+
+    @classmethod
+    def streams(cls, dev):
+        key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+        if key not in cls._streams:
+            cls._streams[key] = [torch.cuda.Stream(device=key) for _ in range(max(1, cls.K))]
+        return cls._streams[key]
+
+    @classmethod
+    def begin(cls, owner, key, dev, covariate, batch):
+        """Start of a model forward.  owner: the module that keeps the plans; key: what the plan depends on (input shape,
+        dtypes, mode flags); covariate: the (B, 1, n) fp32 covariate tensor the conditional layers slice their rows from."""
+        cls._cur = None
+        if not cls.enabled or cls.live > 0 or torch.device(dev).type != "cuda" or SidePrep._on:
+            return
+        plans = owner.__dict__.setdefault("_prep_ahead_plans", {})
+        plan = plans.get(key)
+        if plan is None:
+            cls._cur = {"mode": "record", "plan": [], "i": 0, "res": None, "owner": owner, "key": key}
+            return
+        if plan == "off":
+            return
+        from .layers import cov_rows
+        main = torch.cuda.current_stream(dev)
+        covs = {}
+        for e in plan:                      # (the covariate rows are made on the main stream, before the fork)
+            if e["ncov"] is not None and e["ncov"] not in covs:
+                c = covariate if covariate.shape[-1] == e["ncov"] else covariate[:, :, :e["ncov"]]
+                covs[e["ncov"]] = cov_rows(c, batch, dev)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        sts = cls.streams(dev)
+        for st in sts:
+            st.wait_event(fork)
+        # largest masters first, each to the stream with the least work so far (the order is free: everything is done
+        # before the first layer runs)
+        load = [0] * len(sts)
+        res = [None] * len(plan)
+        for i in sorted(range(len(plan)), key=lambda j: -plan[j]["master"].numel()):
+            e = plan[i]
+            k = load.index(min(load))
+            load[k] += e["master"].numel() + (1 << 18)          # (+ a launch's worth: the tiny layers are not free)
+            st = sts[k]
+            with torch.cuda.stream(st):
+                master = e["master"]
+                r = bm = None
+                if e["ncov"] is not None:
+                    cov = covs[e["ncov"]]
+                    Wr, br, be = e["routing"]
+                    if e["bufs"] is None:
+                        e["bufs"] = [_f32((batch, Wr.shape[0]), dev), _f32((batch, be.shape[1]), dev), None]
+                    r, bm = e["bufs"][0], e["bufs"][1]
+                    check(lib.coma_routing_fwd(ptr(cov), batch, cov.shape[1], ptr(Wr), ptr(br), Wr.shape[0], ptr(be), be.shape[1],
+                                               ptr(r), ptr(bm), L.stream()), "coma_routing_fwd")
+                elif e["bufs"] is None:
+                    e["bufs"] = [None, None, None]
+                if e["bufs"][2] is None:
+                    E_ = master.shape[0] if r is not None else 1
+                    A_, B_ = master.shape[-5], master.shape[-4]
+                    taps_ = master.shape[-1] * master.shape[-2] * master.shape[-3]
+                    cout_, cin_ = (B_, A_) if e["transposed"] else (A_, B_)
+                    Bw_ = batch if r is not None else 1
+                    e["bufs"][2] = (_new((Bw_, taps_, cout_, cin_), e["fwd_dtype"], dev),
+                                    _new((Bw_, taps_, cin_, cout_), e["dgrad_dtype"], dev) if e["dgrad_dtype"] is not None else None)
+                wk_f, wk_d, rr, pmeta = _prep_fwd(master, r, e["transposed"], e["fwd_dtype"], e["dgrad_dtype"], e["bufs"][2])
+                res[i] = (r, bm, wk_f, wk_d, rr, pmeta)
+        for st in sts:
+            main.wait_stream(st)
+        cls._cur = {"mode": "replay", "plan": plan, "i": 0, "res": res, "owner": owner, "key": key}
+
+    @classmethod
+    def note(cls, master, routing, ncov, transposed, fwd_dtype, dgrad_dtype):
+        """Recording forward: this layer prepares `master` this way."""
+        c = cls._cur
+        if c is not None and c["mode"] == "record":
+            c["plan"].append({"master": master, "routing": routing, "ncov": ncov, "transposed": bool(transposed),
+                              "fwd_dtype": fwd_dtype, "dgrad_dtype": dgrad_dtype, "bufs": None})
+
+    @classmethod
+    def take(cls, master, transposed, fwd_dtype, dgrad_dtype):
+        """The next entry's prepared (r, bias_mix, wk_f, wk_d, rr, pmeta) if it is this layer's; else None (and the plan is
+        dropped: the model took another path than the recorded one)."""
+        c = cls._cur
+        if c is None or c["mode"] != "replay":
+            return None
+        i = c["i"]
+        if i < len(c["plan"]):
+            e = c["plan"][i]
+            if e["master"] is master and e["transposed"] == bool(transposed) and e["fwd_dtype"] == fwd_dtype and e["dgrad_dtype"] == dgrad_dtype:
+                c["i"] = i + 1
+                cls.used += 1
+                return c["res"][i]
+        c["mode"] = "broken"
+        c["owner"].__dict__["_prep_ahead_plans"].pop(c["key"], None)
+        return None
+
+    @classmethod
+    def end(cls, ok=True):
+        c, cls._cur = cls._cur, None
+        if c is None:
+            return
+        plans = c["owner"].__dict__.setdefault("_prep_ahead_plans", {})
+        if c["mode"] == "record" and ok and c["plan"]:
+            plans[c["key"]] = c["plan"]
+        elif c["mode"] == "replay" and ok and c["i"] != len(c["plan"]):
+            plans.pop(c["key"], None)          # fewer layers than recorded: record again next time
+
+
 class WgradSide:
     """Weight gradients beside the data-gradient chain.  A layer's weight gradient (MFMA-bound, 1.7 + 0.9 + 0.9 ms per step
     over the thick / strided / thin layers), the scatter of it to the experts and the routing backward feed nothing but the
@@ -506,14 +632,18 @@ class Routing(Function):
     r = sigmoid(cov @ Wr^T + br) (B, E);  bias_mix = r @ bias_e (B, Cout)."""
 
     @staticmethod
-    def forward(ctx, cov, Wr, br, bias_e):
+    def forward(ctx, cov, Wr, br, bias_e, pre=None):
+        """pre: (r, bias_mix) already computed for this forward (PrepAhead) -- the node then only exists for its backward."""
         ctx.set_materialize_grads(False)
         assert cov.dtype == torch.float32 and cov.is_contiguous() and cov.is_cuda
         B, NC = cov.shape
         E, N = Wr.shape[0], bias_e.shape[1]
-        r, bm = _f32((B, E), cov.device), _f32((B, N), cov.device)
-        check(lib.coma_routing_fwd(ptr(cov), B, NC, ptr(Wr), ptr(br), E, ptr(bias_e), N, ptr(r), ptr(bm), L.stream()),
-              "coma_routing_fwd")
+        if pre is not None:
+            r, bm = pre[0].view_as(pre[0]), pre[1].view_as(pre[1])      # (fresh tensor objects: outputs of this node)
+        else:
+            r, bm = _f32((B, E), cov.device), _f32((B, N), cov.device)
+            check(lib.coma_routing_fwd(ptr(cov), B, NC, ptr(Wr), ptr(br), E, ptr(bias_e), N, ptr(r), ptr(bm), L.stream()),
+                  "coma_routing_fwd")
         ctx.save_for_backward(cov, r, bias_e)
         ctx.params = (Wr, br, bias_e)
         return r, bm
@@ -533,7 +663,7 @@ class Routing(Function):
             else:
                 SidePrep.fence(dev)
         with scope:
-            return Routing._backward(cov, r, bias_e, Wr, br, be, dr, dbm, B, NC, E, N, dev)
+            return Routing._backward(cov, r, bias_e, Wr, br, be, dr, dbm, B, NC, E, N, dev) + (None,)
 
     @staticmethod
     def _backward(cov, r, bias_e, Wr, br, be, dr, dbm, B, NC, E, N, dev):
@@ -726,12 +856,18 @@ class ConvLayer(Function):
     master ([E,] A, B, k,k,k); r (B, E) routing or None; bias (Cout,) / per-sample (B, Cout) or None."""
 
     @staticmethod
-    def forward(ctx, x, master, r, bias, ksize, stride, transposed, algo, out, norm, fwd_dtype, dgrad_dtype, bias_zero_grad):
+    def forward(ctx, x, master, r, bias, ksize, stride, transposed, algo, out, norm, fwd_dtype, dgrad_dtype, bias_zero_grad,
+                prepped=None):
+        """prepped: (wk_f, wk_d, rr, pmeta) from PrepAhead (persistent buffers, prepared at the start of this forward)."""
         ctx.set_materialize_grads(False)
         per_sample = r is not None
         form = 1 if transposed else 0
         side = False
-        if SidePrep._on:
+        ctx.ahead = False
+        if prepped is not None:
+            wk_f, wk_d, rr, pmeta = prepped
+            side = None              # (neither the side-stream nor the in-line preparation below)
+        elif SidePrep._on:
             E_ = master.shape[0] if per_sample else 1
             A_, B_ = master.shape[-5], master.shape[-4]
             taps_ = ksize ** 3
@@ -743,16 +879,19 @@ class ConvLayer(Function):
                     wk_f, wk_d, rr, pmeta = _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype, bufs)
                 SidePrep.fence(x.device)
                 side = True
-        if not side:
+        if side is False:
             if SidePrep._on:
                 SidePrep.fence(x.device)      # (routing / bias mix of this layer were queued on the side stream)
             wk_f, wk_d, rr, pmeta = _prep_fwd(master, r, transposed, fwd_dtype, dgrad_dtype)
         y, sums = _conv_fwd(x, wk_f, bias, ksize, stride, form, per_sample, algo, out, norm)
         ctx.save_for_backward(x, wk_d, master, rr)
         ctx.fork = getattr(x, "_coma_fork", None)
-        ctx.side = side
+        ctx.side = bool(side)
         if side and any(ctx.needs_input_grad):
             SidePrep._live += 1
+        if prepped is not None and any(ctx.needs_input_grad):
+            ctx.ahead = True
+            PrepAhead.live += 1
         ctx.p_master, ctx.p_bias = master, (bias if not per_sample else None)
         # per-sample biases survive a BATCH norm (only their batch mean is removed); an instance norm removes them
         removed = norm is not None and (not per_sample or (norm[0] if isinstance(norm, (tuple, list)) else norm) == L.NORM_INSTANCE)
@@ -766,7 +905,9 @@ class ConvLayer(Function):
     @staticmethod
     def backward(ctx, dy, *_unused):
         if dy is None:
-            return (None,) * 13
+            if ctx.ahead:
+                PrepAhead.live = max(0, PrepAhead.live - 1)
+            return (None,) * 14
         x, wk_d, master, rr = ctx.saved_tensors
         ksize, stride, form, per_sample, algo, bias_mode, wshape, pmeta = ctx.meta
         need_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
@@ -779,6 +920,8 @@ class ConvLayer(Function):
         dmaster = dr = None
         if ctx.side:
             SidePrep._live = max(0, SidePrep._live - 1)
+        if ctx.ahead:
+            PrepAhead.live = max(0, PrepAhead.live - 1)
         if wside:
             WgradSide.keep.extend((master, rr))
             with torch.cuda.stream(SidePrep.stream(x.device)):
@@ -798,7 +941,7 @@ class ConvLayer(Function):
                     dmaster, dr = _prep_bwd(dwk, master, rr, pmeta, ctx.p_master)
             else:
                 dmaster, dr = _prep_bwd(dwk, master, rr, pmeta, ctx.p_master)
-        return (dx, dmaster, dr, dbias) + (None,) * 9
+        return (dx, dmaster, dr, dbias) + (None,) * 10
 
 
 # --------------------------------------------------------------------------------------

@@ -472,6 +472,67 @@ def test_side_stream_weight_gradients_equal_one_stream():
         assert rel(g, ref_g) < 5e-3 and torch.equal(p_, ref_p), (mode, rel(g, ref_g))      # (norm / loss reductions use fp32 atomics)
 
 
+def test_weight_preparation_ahead_equals_inline():
+    """ops.PrepAhead: every layer's routing + expert mix at the start of the forward, on two streams beside each other
+    (eager, and as parallel branches of the captured graph), must give the losses, gradients and parameters of the in-line
+    order -- on the deterministic direct kernels (conv_algo=1).  The first forward of a configuration records the plan; a
+    second forward while a backward is still outstanding falls back to the in-line preparation."""
+    import coma_unet_amd as cu
+    from coma_unet_amd import ops
+    from coma_unet_amd.synthetic import make_batch
+    from coma_unet_amd.train import train_step, forward_loss, make_optimizer, GraphedTrainStep
+    S = (32, 32, 32)
+    b = make_batch(2, S, seed=39)
+    res = {}
+    was = ops.PrepAhead.enabled
+    try:
+        for mode in ("inline", "ahead", "ahead-graph"):
+            ops.PrepAhead.enabled = mode != "inline"
+            n0 = ops.PrepAhead.used
+            torch.manual_seed(9)
+            gm = cu.build_model(volume_shape=S, static_prompts=True, conv_algo=1).cuda()
+            gm.set_save_attn(None)
+            gm.train(True)
+            gb = _gpu_batch(b)
+            gb["roi_pred_dicts"] = gm._priors(b["roi_pred_dicts"], 2, torch.device("cuda"))
+            opt = make_optimizer(gm, 0.0)        # lr 0 (weight decay acts through lr too): every step sees the same parameters
+            crit = cu.build_reference_criterion()
+            losses = []
+            if mode == "ahead-graph":
+                step = GraphedTrainStep(gm, crit, opt, gb, warmup=2)        # eager step 1 records, step 2 prepares ahead; then replays
+                for _ in range(2):
+                    losses.append(float(step()[0][0]))
+            else:
+                for _ in range(4):
+                    losses.append(float(train_step(gm, crit, opt, gb)[0][0]))
+            torch.cuda.synchronize()
+            used = ops.PrepAhead.used - n0
+            assert (used == 0) if mode == "inline" else (used >= 60), (mode, used)
+            res[mode] = (losses, opt.flat_g.clone(), opt.flat_p.clone())
+            if mode == "ahead":
+                # a second forward before the backward of the first: the persistent buffers are still needed -> in-line
+                opt.zero_grad()
+                l1, _ = forward_loss(gm, crit, gb)
+                n1 = ops.PrepAhead.used
+                with torch.no_grad():
+                    forward_loss(gm, crit, gb)
+                assert ops.PrepAhead.used == n1 and ops.PrepAhead.live > 0
+                l1[0].backward()
+                torch.cuda.synchronize()
+                assert rel(opt.flat_g, res[mode][1]) < 5e-3
+                opt.zero_grad()          # (layers whose output the loss never reaches see no backward: the step boundary resets the count)
+                assert ops.PrepAhead.live == 0
+    finally:
+        ops.PrepAhead.enabled = was
+    ref_l, ref_g, ref_p = res["inline"]
+    for mode in ("ahead", "ahead-graph"):
+        l, g, p_ = res[mode]
+        print(mode, l, "vs", ref_l)
+        for a in l:
+            assert abs(a - ref_l[0]) <= 1e-5 * abs(ref_l[0]), (mode, l, ref_l)
+        assert rel(g, ref_g) < 5e-3 and torch.equal(p_, ref_p), (mode, rel(g, ref_g))      # (norm / loss reductions use fp32 atomics)
+
+
 def _grad_scale(model):
     return {n: (float(p.grad.abs().max()) if p.grad is not None else 0.0) for n, p in model.named_parameters()}
 
