@@ -161,12 +161,13 @@ _WS_PINNED = set()      # devices whose scratch buffer's address is baked into a
 
 
 def workspace(nbytes: int, device, lane: int = 0) -> torch.Tensor:
-    """Stream-ordered scratch buffer (grown on demand, one per device and `lane`: lane 1 belongs to the side stream of
-    ops.WgradSide, whose kernels run beside the current stream's).  While a captured graph holds the buffer's raw pointer
-    in its kernel arguments (pin_workspace) the cached buffer is never replaced: a larger request gets a one-off
-    allocation instead, so replays keep writing into memory that is still theirs."""
+    """Stream-ordered scratch buffer, grown on demand: one per device, `lane` and CURRENT STREAM (kernels of the side streams --
+    ops.WgradSide's weight gradients, ops.Branch's independent model branches -- run beside the main stream's and must not
+    share its scratch).  While a captured graph holds a buffer's raw pointer in its kernel arguments (pin_workspace) the
+    cached buffers are never replaced: a larger request gets a one-off allocation instead, so replays keep writing into
+    memory that is still theirs."""
     dev = (device.index if device.index is not None else torch.cuda.current_device())
-    key = (dev, lane)
+    key = (dev, lane, torch.cuda.current_stream(dev).cuda_stream if torch.cuda.is_available() else 0)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         new = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
