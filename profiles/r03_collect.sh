@@ -23,7 +23,7 @@ head -12 $O/r03_bf16_kernel_trace_summary.txt
 echo "== side-stream picture"
 python profiles/side_stamps.py > $O/r03_side_stamps.txt 2>&1 || true
 tail -3 $O/r03_side_stamps.txt
-bash profiles/ab_env.sh "COMA_WGRAD_SIDE=0" "COMA_NO_DUO=1" > $O/r03_ab_side_duo.txt 2>&1 || true
+bash profiles/ab_env.sh "COMA_WGRAD_SIDE=0" "COMA_NO_DUO=1" "COMA_PREP_AHEAD=0" > $O/r03_ab_side_duo.txt 2>&1 || true
 cat $O/r03_ab_side_duo.txt
 echo "== microbenchmarks"
 python profiles/microbench_norm.py > $O/r03_microbench_norm.txt 2>&1 || true
