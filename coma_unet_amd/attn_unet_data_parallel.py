@@ -388,7 +388,12 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         projected = [self.projection_heads[i](enc[i]) for i in range(self.depth)]
         m = ops.SpatialMean.apply(out)                                   # AdaptiveAvgPool3d(1)
         lin = self.final_projection_head[1]
-        final_proj = F.relu(F.linear(m.view(-1, 1, 1, 1, 1), lin.weight, lin.bias))   # (B,1,1,1,2048): 2048 numbers of glue
+        # Linear(1 -> 2048) as a broadcast multiply-add: (B,1,1,1,2048), 2048 numbers of glue.  (F.linear sent the backward
+        # through a rocBLAS GEMM of shape (2, 2048) x (2048, 1) that takes 49 us per step.)
+        if lin.in_features == 1:
+            final_proj = F.relu(m.view(-1, 1, 1, 1, 1) * lin.weight.view(-1) + lin.bias)
+        else:
+            final_proj = F.relu(F.linear(m.view(-1, 1, 1, 1, 1), lin.weight, lin.bias))
         if self.embeddings_out:
             return out_ext, projected, final_proj, [to_external(e) for e in enc]
         if self.decoder_ds:
