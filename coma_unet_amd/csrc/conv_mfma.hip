@@ -2236,7 +2236,6 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
   // that the in-volume test of a piece is ONE subtraction against the packed per-tile limits (guard bits 9 / 19 / 29
   // survive iff every field is within its limit); its LDS byte offset ----
   unsigned h_boff[HIT], h_zyx[HIT];
-  int h_lds[HIT];
 #pragma unroll
   for (int it = 0; it < HIT; ++it) {
     const int piece = tid + 256 * it;
@@ -2244,26 +2243,18 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
     const int hx = row % HX, hy = (row / HX) % HY, hz = row / (HX * HY);
     h_boff[it] = (unsigned)((((hz * p.H + hy) * p.W + hx) * p.ldx + ch * EPB) * (int)sizeof(T));
     h_zyx[it] = piece < HP ? ((unsigned)hz << 20) | ((unsigned)hy << 10) | (unsigned)hx : 0x1ff00000u;      // (invalid: beyond any limit)
-    h_lds[it] = row * P + ch * 16;
   }
+  const int h_lds0 = (tid >> 2) * P + (tid & 3) * 16;      // piece `it` of this thread: + it * 64 rows (an immediate, not a register)
   constexpr unsigned GUARD = (1u << 29) | (1u << 19) | (1u << 9);
   // weight piece `it` of this thread: slot 2 it + (tid >> 7), output row n = (tid >> 2) & 31, 16-byte chunk tid & 3; the
   // slot's tap differs between the two passes: both byte offsets are kept (OOB = the empty 14th slot of pass A)
   const int w_s0 = tid >> 7, w_n = (tid >> 2) & 31, w_ch = tid & 3;
   const int w_lds0 = (w_s0 * 32 + w_n) * P + w_ch * 16;
   constexpr int W_LSTEP = 2 * 32 * P;
-  unsigned w_off[2][WIT];
-  {
-    const unsigned w_row = (unsigned)(((long)(n0 + w_n) * p.C + w_ch * EPB) * (long)sizeof(T));
-    const unsigned w_tap = (unsigned)((long)p.N * p.C * (long)sizeof(T));         // bytes between two taps
-#pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2)
-#pragma unroll
-      for (int it = 0; it < WIT; ++it) {
-        const int tap = w_s0 ? TC_TAP[g2][2 * it + 1] : TC_TAP[g2][2 * it];
-        w_off[g2][it] = tap < 27 ? w_row + (unsigned)tap * w_tap : OOB;
-      }
-  }
+  // (the 14 byte offsets of a thread's weight pieces are rebuilt at every fetch -- one multiply-add from a compile-time tap
+  // pair -- instead of living in 14 registers: with the statistics the kernel spilled 28)
+  unsigned w_row = (unsigned)(((long)(n0 + w_n) * p.C + w_ch * EPB) * (long)sizeof(T));
+  const unsigned w_tap = (unsigned)((long)p.N * p.C * (long)sizeof(T));         // bytes between two taps
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, p.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wb), 0, p.wbytes, 0x00020000);
 
@@ -2290,7 +2281,10 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
   };
   // slot 2 it + w_s0 of pass `grp` holds tap TC_TAP[grp][slot] (27 = the empty 14th slot of group A: reads as zero)
   auto w_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int it, int grp, int c0_b) -> tc_u32x4_t {
-    const unsigned voff = grp ? w_off[1][it] : w_off[0][it];
+    const int t0 = grp ? TC_TAP[1][2 * it] : TC_TAP[0][2 * it], t1 = grp ? TC_TAP[1][2 * it + 1] : TC_TAP[0][2 * it + 1];
+    const int tap = w_s0 ? t1 : t0;
+    asm volatile("" : "+v"(w_row));                  // (not hoisted back into loop-invariant registers)
+    const unsigned voff = tap < 27 ? w_row + (unsigned)tap * w_tap : OOB;
     return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, c0_b, 0);
   };
   auto tile_org = [&](int z0, int y0, int x0, int c0) -> unsigned {
@@ -2339,7 +2333,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_tconv_k(TconvP p) {
         __syncthreads();                       // all waves finished reading the previous halo / weights
 #pragma unroll
         for (int it = 0; it < HIT; ++it)
-          if (tid + 256 * it < HP) *reinterpret_cast<tc_u32x4_t*>(Hl + h_lds[it]) = hreg[it];
+          if (tid + 256 * it < HP) *reinterpret_cast<tc_u32x4_t*>(Hl + h_lds0 + it * 64 * P) = hreg[it];
 #pragma unroll
         for (int it = 0; it < WIT; ++it) *reinterpret_cast<tc_u32x4_t*>(Wl + w_lds0 + it * W_LSTEP) = wreg[it];
         __syncthreads();
