@@ -1090,10 +1090,12 @@ __device__ __forceinline__ void duo_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int STATS>
+// LX = 5: tiles of 2 x 4 x 32 voxels (W >= 32); LX = 4: 2 x 8 x 16 (the 16^3 level: an M-tile is two x-rows of 16 voxels)
+template <int STATS, int LX = 5>
 __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
-  constexpr int TX = 32, TY = 4, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
-  constexpr int P = 48, HB = HV * P, WB = 27 * 64 * 16;
+  constexpr int TX = 1 << LX, RY = 32 / TX, TY = 4 * RY, TZ = 2, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HV = HX * HY * HZ;
+  static_assert(HV <= 816, "the halo image is sized for the 2 x 4 x 32 tile");
+  constexpr int P = 48, HB = 816 * P, WB = 27 * 64 * 16;
   constexpr int HP = HV * 2, HIT = (HP + 255) / 256;        // halo pieces of a 16-channel chunk; per thread of a group
   constexpr int WH = 27 * 32, WIT = (WH + 255) / 256;       // weight pieces per half image; per thread of a group
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1137,7 +1139,9 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
 
   // fragment bases: this wave's M-tiles are rows y0, y0 + 1 of plane zq
   const int zq = wq >> 1, y0w = (wq & 1) * 2;
-  const int a_base = ((zq * HY + y0w) * HX + fr) * P + fh * 16;
+  // (LX = 4: M-tile j = 2 wq + i is rows 2 (j & 3), 2 (j & 3) + 1 of plane zq; the lane's voxel is (fr >> 4, fr & 15) in it)
+  const int a_base = LX == 5 ? ((zq * HY + y0w) * HX + fr) * P + fh * 16
+                             : ((zq * HY + y0w * RY + (fr >> LX)) * HX + (fr & (TX - 1))) * P + fh * 16;
   const int w_frag = lane * 16;
 
   // ---- this group's tile walk ----
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
       const bool ok = ((((zyx | GUARD) - lo) & (hi - zyx)) & GUARD) == GUARD;
       const unsigned roff = (unsigned)((((hz * p.H + hy) * p.W + hx) * p.ldx + h_half * 8) * 2);
       const unsigned voff = ok ? org_b + roff : OOB;
-      hx += 26; hy += 3;                               // the next piece: 128 rows = 3 x-lines + 26 voxels on
+      hx += 128 % HX; hy += 128 / HX;                  // the next piece: 128 rows = 3 x-lines + 26 voxels on (LX = 4: 7 + 2)
       if (hx >= HX) { hx -= HX; ++hy; }
       if (hy >= HY) { hy -= HY; ++hz; }
       hreg[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
@@ -1275,12 +1279,15 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         }
         const char* Wc = Wl + ((ph >> 1) & 1) * WB + w_frag;
-        uint4 wg[2][3], xr[2][4];
+        // xr: LX = 5 the four halo rows y .. y + 3 the wave's two y-neighbour M-tiles share; LX = 4 rows ky + 2 i of the
+        // two M-tiles (each two x-rows high: a tap shift by one row gives different fragments: six reads, rows 0 .. 4)
+        constexpr int NXR = LX == 5 ? 4 : 5;
+        uint4 wg[2][3], xr[2][NXR];
         auto rdg = [&](int g, int bf) {
           const int kz = g / 3, kx = g % 3;
           const int toff = (kz * HY * HX + kx) * P;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) xr[bf][r] = *reinterpret_cast<const uint4*>(Hl + a_base + toff + r * HX * P);
+          for (int r = 0; r < NXR; ++r) xr[bf][r] = *reinterpret_cast<const uint4*>(Hl + a_base + toff + r * HX * P);
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) wg[bf][ky] = *reinterpret_cast<const uint4*>(Wc + (kz * 9 + ky * 3 + kx) * 1024);
         };
@@ -1291,7 +1298,7 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i] = mma_piece(wg[g & 1][ky], xr[g & 1][i + ky], acc[i], bf16_t());
+            for (int i = 0; i < 2; ++i) acc[i] = mma_piece(wg[g & 1][ky], xr[g & 1][RY * i + ky], acc[i], bf16_t());
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -1339,7 +1346,7 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_duo_k(Halo2P p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int j = wq * 2 + i;
-          const int gz = z0 + (j >> 2), gy = y0 + (j & 3), gx = x0 + fr;
+          const int gz = z0 + (j >> 2), gy = y0 + (j & 3) * RY + (fr >> LX), gx = x0 + (fr & (TX - 1));
           const bool valid = gz < p.D && gy < p.H && gx < p.W;
           unsigned pk[4][2];
 #pragma unroll
@@ -2654,7 +2661,7 @@ static int launch_halo(const HaloP& p0, int B, hipStream_t s) {
 static bool aligned16(const void* p);
 static size_t duo_frag_bytes(const coma_conv_desc* d, const coma_tensor* x, const coma_tensor* y) {
   static const bool on = getenv("COMA_DUO_C32_ONLY") == nullptr && getenv("COMA_NO_DUO") == nullptr;
-  if (!on || x->dtype != COMA_BF16 || d->ksize != 3 || d->stride != 1 || x->W < 32) return 0;
+  if (!on || x->dtype != COMA_BF16 || d->ksize != 3 || d->stride != 1 || x->W < 16) return 0;
   if (x->C < 64 || x->C % 16 || y->C % 32) return 0;
   return (size_t)(d->per_sample_w ? x->B : 1) * 27 * y->C * x->C * 2;
 }
@@ -2709,7 +2716,7 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
       return 0;
     }
   }
-  if (lx == 5 && (thin || vec)) {
+  if ((lx == 5 && (thin || vec)) || (lx == 4 && !F32 && !thin && vec)) {      // (lx == 4: the two-group kernel only)
     Halo2P q;
     q.x = p.x; q.ldx = p.ldx; q.sbx = p.sbx; q.D = p.D; q.H = p.H; q.W = p.W; q.C = p.C;
     q.y = p.y; q.ldy = p.ldy; q.sby = p.sby; q.N = p.N; q.w = p.w; q.wsb = p.wsb; q.bias = p.bias; q.bsb = p.bsb;
@@ -2722,7 +2729,8 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     q.stats = nullptr; q.stats_inst = stats_inst;
     q.st8 = y->ld % 4 == 0 && y->sb % 4 == 0 && (((uintptr_t)y->data) & 7) == 0;
     q.st16 = y->ld % EPB == 0 && y->sb % EPB == 0 && (((uintptr_t)y->data) & 15) == 0;
-    q.ntx = (q.W + 31) / 32; q.nty = (q.H + 3) / 4; q.ntz = (q.D + 1) / 2;
+    const int txv = lx == 5 ? 32 : 16, tyv = lx == 5 ? 4 : 8;      // tile: 2 x 4 x 32 voxels, or 2 x 8 x 16 on the 16-wide grids
+    q.ntx = (q.W + txv - 1) / txv; q.nty = (q.H + tyv - 1) / tyv; q.ntz = (q.D + 1) / 2;
     q.ids_total = q.ntx * q.nty * ((q.ntz + 7) / 8) * 8;
     const int nblk_n = (q.N + 31) / 32;
     int gx = (thin ? 1024 : 512) / (nblk_n * x->B);   // thin: 2 blocks per CU, thick: 1
@@ -2764,17 +2772,26 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
         const size_t lds2 = (size_t)2 * 34 * 6 * 4 * 48 + (size_t)2 * 27 * 64 * 16 + 128;
         static bool attr2 = false;
         if (!attr2) {
-          (void)hipFuncSetAttribute((const void*)conv_mfma_duo_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          (void)hipFuncSetAttribute((const void*)conv_mfma_duo_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute((const void*)conv_mfma_duo_k<0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute((const void*)conv_mfma_duo_k<1, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute((const void*)conv_mfma_duo_k<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute((const void*)conv_mfma_duo_k<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           attr2 = true;
         }
-        coma_set_kernel_tag("conv_mfma_duo_k<%d>", stats ? 1 : 0);
-        if (stats) hipLaunchKernelGGL((conv_mfma_duo_k<1>), grid2, dim3(512), lds2, s, q);
-        else hipLaunchKernelGGL((conv_mfma_duo_k<0>), grid2, dim3(512), lds2, s, q);
+        if (lx == 5) {
+          coma_set_kernel_tag("conv_mfma_duo_k<%d, 5>", stats ? 1 : 0);
+          if (stats) hipLaunchKernelGGL((conv_mfma_duo_k<1, 5>), grid2, dim3(512), lds2, s, q);
+          else hipLaunchKernelGGL((conv_mfma_duo_k<0, 5>), grid2, dim3(512), lds2, s, q);
+        } else {
+          coma_set_kernel_tag("conv_mfma_duo_k<%d, 4>", stats ? 1 : 0);
+          if (stats) hipLaunchKernelGGL((conv_mfma_duo_k<1, 4>), grid2, dim3(512), lds2, s, q);
+          else hipLaunchKernelGGL((conv_mfma_duo_k<0, 4>), grid2, dim3(512), lds2, s, q);
+        }
         COMA_LAUNCH_CHECK();
         return 0;
       }
     }
+    if (lx == 5) {
     constexpr int HV2 = 34 * 6 * 4;
     const bool resident = thin || (!F32 && q.C == 32);
     // C >= 64: all 27 taps of the current 32-channel chunk in LDS, refetched per chunk (RESIDENT = 2).  The 9-taps-per-
@@ -2803,6 +2820,8 @@ static int conv_mfma_halo(const coma_conv_desc* d, const coma_tensor* x, const v
     }
     COMA_LAUNCH_CHECK();
     return 0;
+    }
+    if (stats_chunks) *stats_chunks = 0;      // (lx == 4 and not taken by the two-group kernel: the first-generation kernel below, no fused statistics)
   }
   if constexpr (F32) {
     if (lx == 5) return launch_halo<16, 5, 1, float>(p, x->B, s);

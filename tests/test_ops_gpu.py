@@ -921,6 +921,8 @@ def test_tconv_halo_kernel_stats_and_accumulate(dims, dtype):
     (64, 32, (5, 9, 40), "dgrad"), (32, 32, (3, 5, 33), "dgrad"),
     # more than two 16-channel chunks: the weights go through the fragment-order re-layout (duo_relayout_k) and are refetched per step
     (64, 32, (5, 7, 45), "fwd"), (128, 64, (4, 8, 32), "fwd"), (32, 64, (3, 5, 40), "dgrad"), (64, 128, (2, 8, 64), "dgrad"),
+    # the 16-wide form (2 x 8 x 16 tiles, an M-tile = two x-rows): exact and ragged grids, many chunks, two output tiles
+    (32, 32, (4, 16, 16), "fwd"), (64, 64, (5, 9, 20), "fwd"), (256, 32, (2, 8, 31), "fwd"), (32, 64, (3, 17, 16), "dgrad"),
 ])
 def test_duo_kernel_matches_fp64_reference(case):
     """conv_mfma_duo_k (two 4-wave groups per CU alternating matrix and staging phases; the thick stride-1 layers):
@@ -941,7 +943,7 @@ def test_duo_kernel_matches_fp64_reference(case):
         wk_f, _ = ops.PrepWeights.apply(master.cuda(), r.cuda(), False, torch.bfloat16, None)
         y, sums = ops._conv_fwd(to_int(x).to("cuda", torch.bfloat16), wk_f, bias.cuda(), 3, 1, 0, True, 2, None, L.NORM_INSTANCE)
         tag = lib.coma_last_kernel().decode()
-        assert tag == "conv_mfma_duo_k<1>", tag
+        assert tag == "conv_mfma_duo_k<1, %d>" % (5 if dims[2] >= 32 else 4), tag
         assert torch.isfinite(y.float()).all() and rel(to_ext(y), yr) < 5e-3, rel(to_ext(y), yr)
         mean, rstd = ops.stats_from_sums(sums, B, cout, dims[0] * dims[1] * dims[2], 1e-5)
         yf = y.double()
@@ -956,14 +958,14 @@ def test_duo_kernel_matches_fp64_reference(case):
         xi = torch.empty((B, *dims, cin), dtype=torch.bfloat16, device="cuda")
         dx, _, _ = ops._conv_bwd(xi, wk_d, to_int(dy).to("cuda", torch.bfloat16), 3, 1, 0, True, 2, (B, 27, cout, cin), True, False, 0, None)
         tag = lib.coma_last_kernel().decode()
-        assert tag == "conv_mfma_duo_k<0>", tag
+        assert tag == "conv_mfma_duo_k<0, %d>" % (5 if dims[2] >= 32 else 4), tag
         assert torch.isfinite(dx.float()).all() and rel(to_ext(dx), dxr) < 5e-3, rel(to_ext(dx), dxr)
 
 
 DISPATCH_ROWS = [
     # cin, cout, k, stride, transposed, coarse/in dims, dtype -> kernel that must run forward / data gradient / weight gradient
-    (32, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_duo_k<0>", "conv_mfma_duo_k<0>", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
-    (64, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_duo_k<0>", "conv_mfma_duo_k<0>", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
+    (32, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_duo_k<0, 5>", "conv_mfma_duo_k<0, 5>", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
+    (64, 32, 3, 1, False, (4, 8, 32), torch.bfloat16, "conv_mfma_duo_k<0, 5>", "conv_mfma_duo_k<0, 5>", "conv_mfma_wgrad2_k<1, 2, 3, 1>"),
     (64, 32, 3, 2, True, (3, 4, 33), torch.bfloat16, "conv_mfma_tconv_k<__bf16", "conv_mfma_gather_k<64, 0, __bf16>", "conv_bf16_wgrad16_k<2, 1>"),
     (32, 64, 3, 2, False, (6, 8, 66), torch.bfloat16, "conv_mfma_gather_k<64, 0, __bf16>", "conv_mfma_tconv_k<__bf16, 0>", "conv_bf16_wgrad16_k<2, 0>"),
     (64, 32, 3, 2, True, (3, 4, 33), torch.float32, "conv_mfma_tconv_k<float", "conv_mfma_gather_k<64, 0, float>", "conv_f32_wgrad16_k<2, 1>"),
