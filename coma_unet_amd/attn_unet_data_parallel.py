@@ -20,6 +20,8 @@ from __future__ import annotations
 from typing import Sequence
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -322,7 +324,8 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
                 tab[b, i, 1] = np.nan_to_num(d["std"])
         return torch.from_numpy(tab).to(device)
 
-    def _modulator_with_uq(self, xi, covariate, roi_pred_dicts, sample_roi_mask, unet_out_dst, prompt_use=(True, True)):
+    def _modulator_with_uq(self, xi, covariate, roi_pred_dicts, sample_roi_mask, unet_out_dst, prompt_use=(True, True),
+                           after_unet=None):
         """attn_unet_data_parallel.py:630-658 on internal tensors.  ``unet_out_dst(cat_a)`` runs the U-Net and
         makes its reduce conv write straight into channel 1 of the (modulated_prompt, out) buffer."""
         cfg = self.cfg
@@ -332,6 +335,8 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         cat_a = ops._new((B, D, H, W, 2), dt, dev)   # cat((modulated_prompt, out)) :654
         cat_b = ops._new((B, D, H, W, 2), dt, dev)   # cat((out, fusion(...)))     :654
         out_a, enc, dec = unet_out_dst(cat_a[..., 1:2])
+        if after_unet is not None:
+            after_unet(enc)          # (the projection heads: queued here, beside the tail below)
         out_b = ops.Copy.apply(out_a, Out(cat_b[..., 0:1]))
         prior = self._priors(roi_pred_dicts, B, dev)
         abeta = covariate.reshape(B, -1)[:, 0].to(device=dev, dtype=torch.float32).contiguous()
@@ -380,12 +385,37 @@ class ContrastiveAttentionUNET_DP(ObservableAttentionUnet):
         else:
             ab = covariate.reshape(x.shape[0], -1)[:, 0].tolist()
             use = (any(a == 1 for a in ab), any(a != 1 for a in ab))
+        # The five projection heads (two 1x1x1 convolutions to ONE channel with their norms each: ~30 launches of 5-30 us) need
+        # the encoder features only.  They are queued right behind the U-Net on an idle side stream (one of ops.PrepAhead's),
+        # so that they run beside the full-resolution tail instead of behind it; the main stream waits for them at the end.
+        want_proj = self.training or self.embeddings_out
+        side = {"projected": None, "stream": None}
+
+        def heads(enc_):
+            dev = enc_[0].device
+            if (ops.PrepAhead.enabled and not ops.SidePrep._on and dev.type == "cuda" and not ops.KernelTimer.enabled
+                    and os.environ.get("COMA_HEADS_SIDE", "1") != "0"):
+                st = ops.PrepAhead.streams(dev)[0]
+                st.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(st):
+                    side["projected"] = [self.projection_heads[i](enc_[i]) for i in range(self.depth)]
+                side["stream"] = st
+                if st not in ops.PrepAhead.branch_streams:
+                    ops.PrepAhead.branch_streams.append(st)
         out, enc, _dec = self._modulator_with_uq(xi, covariate, roi_pred_dicts, sample_roi_mask,
-                                                 lambda dst: self._unet(xi, covariate, out=dst), use)
+                                                 lambda dst: self._unet(xi, covariate, out=dst), use,
+                                                 heads if want_proj else None)
         out_ext = to_external(out)
-        if not self.training and not self.embeddings_out:
+        if not want_proj:
             return out_ext
-        projected = [self.projection_heads[i](enc[i]) for i in range(self.depth)]
+        if side["projected"] is not None:
+            projected = side["projected"]
+            cur = torch.cuda.current_stream(out.device)
+            cur.wait_stream(side["stream"])
+            for t in projected:
+                t.record_stream(cur)
+        else:
+            projected = [self.projection_heads[i](enc[i]) for i in range(self.depth)]
         m = ops.SpatialMean.apply(out)                                   # AdaptiveAvgPool3d(1)
         lin = self.final_projection_head[1]
         # Linear(1 -> 2048) as a broadcast multiply-add: (B,1,1,1,2048), 2048 numbers of glue.  (F.linear sent the backward

@@ -349,6 +349,9 @@ class SidePrep:
     def join(cls):
         for key, st in cls._streams.items():
             torch.cuda.current_stream(key).wait_stream(st)
+        for st in PrepAhead.branch_streams:              # (model branches queued on an idle preparation stream write gradients through too)
+            torch.cuda.current_stream(st.device).wait_stream(st)
+        PrepAhead.branch_streams.clear()
         cls._on = False
         WgradSide.joined()
 
@@ -385,6 +388,7 @@ class PrepAhead:
     K = int(os.environ.get("COMA_PREP_AHEAD_STREAMS", "2"))
     _streams = {}
     _cur = None        # the running forward: {"mode", "plan", "i", "res", "owner", "key"}
+    branch_streams = []  # preparation streams a model branch ran on in this step (the projection heads): joined with the side stream
     live = 0           # ConvLayer nodes whose backward still reads the persistent buffers
     used = 0           # layers served from the up-front preparation so far (diagnostic / tests)
 
