@@ -28,6 +28,13 @@ import os
 import sys
 import time
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # N > 1: the exchange's streams (the auxiliary stream behind the graph's bucket events, the process group's own) should
+    # not share a hardware queue with the replayed graph's streams, or their work is only SEEN when the graph's packets in
+    # front of it have drained (profiles/external_event_probe.py).  The runtime's default is 4 queues; the one-GPU step is
+    # insensitive to the setting (17.08 / 17.07 / 17.04 ms at 4 / 8 / 6).  Must be set before HIP initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -402,7 +409,10 @@ def main():
             dp_info = {"mode": args.dp, "exchange_ms": round(float(tt[0]), 3), "local_step_ms": round(float(tt[1]), 3),
                        "exposed_ms": round(elapsed / args.steps * 1e3 - float(tt[1]), 3),
                        "gradient_mb": round(opt.flat_g.numel() * 4 / 2 ** 20, 1),
-                       "early_buckets": getattr(reducer, "early", None)}
+                       "early_buckets": getattr(reducer, "early", None),
+                       # torch mode under graph replay: were buckets sent from behind external events of the graph
+                       # (data_parallel.GraphBucketWatch)?  "node" = yes; anything else = exchange behind the graph, and why
+                       "graph_overlap": getattr(reducer, "watch_probe", None)}
         except Exception as e:
             dp_info = {"mode": args.dp, "error": f"{type(e).__name__}: {e}"}
     loss = float(last[0])

@@ -91,6 +91,10 @@ SIGNATURES = {
     "coma_reduce_scatter_sum_f32": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "coma_allgather_f32": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "coma_broadcast_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "coma_event_create": (_i32, [C.POINTER(C.c_void_p)]),
+    "coma_event_destroy": (_i32, [_vp]),
+    "coma_event_record_external": (_i32, [_vp, _vp]),
+    "coma_stream_wait_external": (_i32, [_vp, _vp]),
     "coma_adamw": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
 }
 

@@ -125,3 +125,55 @@ extern "C" int coma_broadcast_f32(void* comm, float* buf, int64_t n, int32_t roo
   ncclResult_t e = r->Broadcast(buf, buf, (size_t)n, ncclFloat32, root, (ncclComm_t)comm, (hipStream_t)stream);
   return e == ncclSuccess ? 0 : fail(r, e, "ncclBroadcast");
 }
+
+/* ---- external events: a record node inside a captured step graph that streams OUTSIDE the graph can wait for ------------ */
+extern "C" int coma_event_create(void** event_out) {
+  COMA_CHECK(event_out, "event_create: bad argument");
+  hipEvent_t e = nullptr;
+  hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  if (rc != hipSuccess) { coma_set_error("hipEventCreateWithFlags: %s", hipGetErrorString(rc)); return 2; }
+  *event_out = (void*)e;
+  return 0;
+}
+
+extern "C" int coma_event_destroy(void* event) {
+  if (!event) return 0;
+  hipError_t rc = hipEventDestroy((hipEvent_t)event);
+  if (rc != hipSuccess) { coma_set_error("hipEventDestroy: %s", hipGetErrorString(rc)); return 2; }
+  return 0;
+}
+
+extern "C" int coma_event_record_external(void* event, void* stream) {
+  COMA_CHECK(event, "event_record_external: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  hipError_t rc = hipStreamGetCaptureInfo_v2(s, &st, &id, &graph, &deps, &ndeps);
+  if (rc != hipSuccess) { (void)hipGetLastError(); coma_set_error("hipStreamGetCaptureInfo_v2: %s", hipGetErrorString(rc)); return 2; }
+  if (st != hipStreamCaptureStatusActive) {
+    rc = hipEventRecord((hipEvent_t)event, s);
+    if (rc != hipSuccess) { (void)hipGetLastError(); coma_set_error("hipEventRecord: %s", hipGetErrorString(rc)); return 2; }
+    return 0;
+  }
+  // the record becomes a NODE of the graph being captured, behind everything the stream has captured so far, and the
+  // stream's later work depends on that node (which orders nothing: the node only stamps the event)
+  hipGraphNode_t node = nullptr;
+  rc = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, (hipEvent_t)event);
+  if (rc != hipSuccess) { (void)hipGetLastError(); coma_set_error("hipGraphAddEventRecordNode: %s", hipGetErrorString(rc)); return 2; }
+  rc = hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies);
+  if (rc != hipSuccess) { (void)hipGetLastError(); coma_set_error("hipStreamUpdateCaptureDependencies: %s", hipGetErrorString(rc)); return 2; }
+  return 0;
+}
+
+extern "C" int coma_stream_wait_external(void* stream, void* event) {
+  COMA_CHECK(event, "stream_wait_external: bad argument");
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing((hipStream_t)stream, &st);
+  COMA_CHECK(st != hipStreamCaptureStatusActive, "stream_wait_external: the waiting stream must be outside the capture");
+  hipError_t rc = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+  if (rc != hipSuccess) { (void)hipGetLastError(); coma_set_error("hipStreamWaitEvent(external): %s", hipGetErrorString(rc)); return 2; }
+  return 0;
+}

@@ -155,18 +155,52 @@ class GradReducer:
             if id(p) not in opt._flat_ids and p.grad is not None:
                 dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
 
-    def reduce_flat_and_step(self):
+    def graph_watch(self, device):
+        """A GraphBucketWatch for a step about to be captured, or None (one rank, switched off by COMA_DP_GRAPH_OVERLAP=0,
+        or the machine's external events do not behave: ``self.watch_probe`` says which)."""
+        import os
+        self.watch_probe = "off"
+        if self.world == 1 and os.environ.get("COMA_DP_GRAPH_OVERLAP") != "force":
+            return None
+        if os.environ.get("COMA_DP_GRAPH_OVERLAP", "1") == "0" or not self.opt.built:
+            return None
+        self.watch_probe = GraphBucketWatch.probe(device)
+        if self.watch_probe != "node":
+            return None
+        return GraphBucketWatch(self.opt, self.bucket_elems)
+
+    def reduce_flat_and_step(self, watch=None):
         """reduce_flat + optimizer.step(), pipelined: every bucket's all-reduce is queued up front (they run one after the
         other on the process group's stream) and each bucket's slice of the AdamW step is launched as soon as ITS all-reduce
-        has finished -- the optimizer's 0.9 ms run under the remaining buckets' exchange instead of after it."""
+        has finished -- the optimizer's 0.9 ms run under the remaining buckets' exchange instead of after it.
+        watch (GraphBucketWatch of the graph just replayed): the buckets it holds events for are queued on an auxiliary
+        stream behind their event, i.e. while the replayed backward is still running; the rest behind the graph."""
         opt = self.opt
         if self.world == 1:
             opt.step()
             return
         assert opt.built, "reduce_flat_and_step needs the flat gradient layout (run two eager steps first)"
         n = opt.flat_g.numel()
-        spans = [(s, min(self.bucket_elems, n - s)) for s in range(0, n, self.bucket_elems)]
-        works = [dist.all_reduce(opt.flat_g[s:s + k], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, k in spans]
+        if watch is not None:
+            if getattr(self, "_aux", None) is None:
+                self._aux = torch.cuda.Stream()
+            spans, works, done = [], [], set()
+            for todo, evs in watch.groups:
+                watch.wait(evs, self._aux)
+                with torch.cuda.stream(self._aux):
+                    for i in todo:
+                        s0, e0 = watch.bounds[i]
+                        spans.append((s0, e0 - s0))
+                        works.append(dist.all_reduce(opt.flat_g[s0:e0], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                        done.add(i)
+            self.early = len(done)
+            for i, (s0, e0) in enumerate(watch.bounds):
+                if i not in done:
+                    spans.append((s0, e0 - s0))
+                    works.append(dist.all_reduce(opt.flat_g[s0:e0], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            spans = [(s, min(self.bucket_elems, n - s)) for s in range(0, n, self.bucket_elems)]
+            works = [dist.all_reduce(opt.flat_g[s:s + k], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, k in spans]
         loose = [p for p in opt.param_groups[0]["params"] if id(p) not in opt._flat_ids and p.grad is not None]
         lworks = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for p in loose]
         for i, ((s, k), w) in enumerate(zip(spans, works)):
@@ -206,6 +240,172 @@ class GradReducer:
         rest = [p for p in params if id(p) not in opt._flat_ids and p.grad is not None]
         for p in rest:
             dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+
+
+class ExternalEvent:
+    """A HIP event recorded as an event-record NODE of the graph being captured and waited for by streams outside the graph
+    (coma_event_record_external / coma_stream_wait_external of the C ABI; this PyTorch build refuses
+    ``torch.cuda.Event(external=True)`` on ROCm)."""
+    __slots__ = ("h",)
+
+    def __init__(self):
+        import ctypes
+        from ._lib import check, lib
+        h = ctypes.c_void_p()
+        check(lib.coma_event_create(ctypes.byref(h)), "coma_event_create")
+        self.h = h.value
+
+    def record(self, stream=None):
+        from ._lib import check, lib
+        st = stream if stream is not None else torch.cuda.current_stream()
+        check(lib.coma_event_record_external(self.h, st.cuda_stream), "coma_event_record_external")
+
+    def wait(self, stream):
+        from ._lib import check, lib
+        check(lib.coma_stream_wait_external(stream.cuda_stream, self.h), "coma_stream_wait_external")
+
+    def __del__(self):
+        try:
+            from ._lib import lib
+            if self.h:
+                lib.coma_event_destroy(self.h)
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+class GraphBucketWatch:
+    """Gradient exchange of the graph-replayed step overlapped with its backward WITHOUT a collective inside the graph.
+    While forward + backward are being captured this object listens to the gradient sink (``ops.GradSink.observer``): when
+    the last write-through gradient of a bucket of the flat buffer has been enqueued, an EXTERNAL event
+    (``ExternalEvent``: ``hipGraphAddEventRecordNode``, an event-record node of the graph) is recorded
+    behind it.  After every ``graph.replay()`` the host makes an auxiliary stream wait for those events
+    and queues the buckets' ``torch.distributed`` all-reduces there: they run beside the rest of the replayed backward, the
+    same way hook-driven buckets do in an eager step.  Buckets that hold a gradient autograd accumulates (not written
+    through) or that complete with the very last kernels have no event and go out behind the graph.
+
+    The gradient kernels run on several streams of the captured step (``ops.WgradSide``'s side stream, the preparation
+    streams the projection heads were queued on): a group of buckets gets ONE EVENT PER STREAM, each recorded in its own
+    stream's order with no edge between the streams, and the exchange waits for all of them.  (One node that depends on
+    several streams is seen from outside only when the whole graph has finished: the runtime enqueues a graph level by
+    level and makes such a node wait for whatever its parents' queues hold by then, which on the shorter side branch is
+    everything -- measured, profiles/external_event_probe.py and dp_watch_timeline.py.  A node with a single parent in its
+    own chain is seen when that parent is done.)  Nothing here adds a dependency to a kernel or disables the two-stream step.
+
+    ``probe()`` checks on the running machine that a stream wait issued after ``hipGraphLaunch`` really waits for the
+    event-record node of that launch (and not for the whole graph, and not for nothing): the overlap is used only where it
+    reports "node"."""
+
+    _probe = {}
+
+    def __init__(self, optimizer, bucket_elems):
+        opt = self.opt = optimizer
+        assert opt.built, "the flat gradient layout exists after the first optimizer step"
+        n = opt.flat_g.numel()
+        bounds, start = [], 0
+        for p in opt._flat_params:
+            off, k = opt._offsets[id(p)]
+            if off + k - start >= bucket_elems:
+                bounds.append((start, off + k))
+                start = off + k
+        if start < n:
+            bounds.append((start, n))
+        self.bounds = bounds
+        self._p2b, self._total = {}, [0] * len(bounds)
+        bi = 0
+        for p in opt._flat_params:
+            off, k = opt._offsets[id(p)]
+            while off >= bounds[bi][1]:
+                bi += 1
+            self._p2b[id(p)] = bi                    # (cut at parameter boundaries: one bucket per parameter)
+            self._total[bi] += 1
+        self.groups = []          # [(bucket indices, external event)] in the order they complete during backward
+        self._left, self._pending, self._main = None, [], None
+
+    @classmethod
+    def probe(cls, device):
+        """"node": a wait issued after the launch waits for the event-record node; "graph": it waits for more (correct, no
+        overlap); "none": it does not wait (unusable); "error: ...": external events cannot be captured here."""
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        if key in cls._probe:
+            return cls._probe[key]
+        res = "node"
+        try:
+            with torch.cuda.device(key):
+                x = torch.zeros(1, device="cuda")
+                ev = ExternalEvent()
+                aux = torch.cuda.Stream()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(aux):             # (first uses load code objects: not inside the timed window)
+                    x.fill_(0.0)
+                    x.clone()
+                    torch.cuda._sleep(1000)
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    torch.cuda._sleep(10_000_000)
+                    x.fill_(1.0)
+                    ev.record()
+                    torch.cuda._sleep(40_000_000)
+                    x.fill_(2.0)
+                for _ in range(2):                   # (the second replay: the event must follow the NEW launch)
+                    x.zero_()
+                    torch.cuda.synchronize()
+                    g.replay()
+                    ev.wait(aux)
+                    with torch.cuda.stream(aux):
+                        y = x.clone()
+                    torch.cuda.synchronize()
+                    v = float(y)
+                    if v == 0.0:
+                        res = "none"
+                    elif v == 2.0 and res == "node":
+                        res = "graph"
+        except Exception as e:                       # noqa: BLE001 -- any failure simply means: exchange behind the graph
+            res = f"error: {type(e).__name__}: {e}"
+            torch.cuda.synchronize()
+        cls._probe[key] = res
+        return res
+
+    # -- inside the capture ---------------------------------------------------------------------------------------
+    def begin(self):
+        """Right before ``backward()`` of the step being captured."""
+        from . import ops
+        self._left = list(self._total)
+        self._pending, self.groups = [], []
+        self._main = torch.cuda.current_stream()
+        ops.GradSink.observer = self
+
+    def mark(self, p):
+        i = self._p2b.get(id(p))
+        if i is not None:
+            self._left[i] -= 1
+            if self._left[i] == 0:
+                self._pending.append(i)
+
+    def flush_pending(self):
+        """Called at the next sink request: every kernel of the earlier requests has been enqueued on its stream."""
+        if not self._pending:
+            return
+        from . import ops
+        todo, self._pending = self._pending, []
+        evs = []
+        for st in {self._main, ops.SidePrep.stream(self._main.device), *ops.PrepAhead.branch_streams}:
+            with torch.cuda.stream(st):
+                capturing = torch.cuda.is_current_stream_capturing()
+            if capturing:                                # (a stream that is not part of the capture holds none of this step's kernels)
+                ev = ExternalEvent()
+                ev.record(st)
+                evs.append(ev)
+        self.groups.append((todo, evs))
+
+    def wait(self, group_events, stream):
+        for ev in group_events:
+            ev.wait(stream)
+
+    def end(self):
+        """Right after ``backward()``."""
+        from . import ops
+        ops.GradSink.observer = None
+        self._pending = []
 
 
 class TorchComm:

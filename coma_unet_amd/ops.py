@@ -208,6 +208,7 @@ class GradSink:
     Post-accumulate-grad hooks do not fire for sunk gradients, so hook-driven overlap keeps this off."""
     written = set()
     listener = None      # data_parallel.StreamedGradExchange: told which gradient slots have been written
+    observer = None      # data_parallel.GraphBucketWatch: the same notifications, passively (the two-stream step stays on)
 
     @classmethod
     def begin_step(cls):
@@ -227,6 +228,8 @@ class GradSink:
         bucket completed by the first one before the node's single kernel was enqueued: the collective read zeros.)"""
         if cls.listener is not None:
             cls.listener.flush_pending()
+        if cls.observer is not None:
+            cls.observer.flush_pending()
         out = []
         for p in params:
             if p is None or not getattr(p, "_coma_sink", False) or p.grad is None or id(p) in cls.written:
@@ -235,6 +238,8 @@ class GradSink:
             cls.written.add(id(p))
             if cls.listener is not None:
                 cls.listener.mark(p)
+            if cls.observer is not None:
+                cls.observer.mark(p)
             out.append(p.grad)
         return out
 

@@ -111,6 +111,9 @@ class GraphedTrainStep:
         model, criterion, optimizer, reducer = self.model, self.criterion, self.optimizer, self.reducer
         torch.cuda.synchronize()
         self._captured_hyper = self._hyper()
+        self.watch = None
+        if reducer is not None and not self.in_graph and hasattr(reducer, "graph_watch"):
+            self.watch = reducer.graph_watch(self.batch["mri"].device)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread may query events while this thread captures
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
@@ -119,7 +122,13 @@ class GraphedTrainStep:
             else:
                 optimizer.zero_grad()
                 self.losses, self.outputs = forward_loss(model, criterion, self.batch)
-                self.losses[0].backward()
+                if self.watch is not None:       # external events behind every completed gradient bucket (GraphBucketWatch)
+                    self.watch.begin()
+                try:
+                    self.losses[0].backward()
+                finally:
+                    if self.watch is not None:
+                        self.watch.end()
                 ops.SidePrep.join()
                 ops.ZeroArena.end_step()      # the clearing memset of the step's zeroed arena belongs INSIDE the replayed part
         if reducer is None or self.in_graph:
@@ -141,7 +150,7 @@ class GraphedTrainStep:
         if whole:
             self.optimizer._flat_step += 1
         else:
-            self.reducer.reduce_flat_and_step()
+            self.reducer.reduce_flat_and_step(watch=self.watch)
         return self.losses, self.outputs
 
 

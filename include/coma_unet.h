@@ -312,6 +312,17 @@ int coma_reduce_scatter_sum_f32(void* comm, const float* send, float* recv, int6
 int coma_allgather_f32(void* comm, const float* send, float* recv, int64_t n_per_rank, void* stream);
 int coma_broadcast_f32(void* comm, float* buf, int64_t n, int32_t root, void* stream);            /* in place */
 
+/* External events (the data-parallel exchange of a graph-replayed step WITHOUT a collective inside the graph;
+ * coma_unet_amd/data_parallel.py GraphBucketWatch).  coma_event_record_external called on a stream that is being captured
+ * adds an event-record node to the graph (hipGraphAddEventRecordNode behind the capture's current dependencies) instead of an internal
+ * dependency; after every launch of the graph a stream OUTSIDE it can wait for that node with coma_stream_wait_external
+ * (hipStreamWaitEvent) and run a bucket's all-reduce beside the rest of the replayed backward.
+ * Outside a capture both behave as plain record / wait.  Events are created without timing.                          */
+int coma_event_create(void** event_out);
+int coma_event_destroy(void* event);
+int coma_event_record_external(void* event, void* stream);
+int coma_stream_wait_external(void* stream, void* event);
+
 #ifdef __cplusplus
 }
 #endif
