@@ -167,7 +167,10 @@ class GradReducer:
         self.watch_probe = GraphBucketWatch.probe(device)
         if self.watch_probe != "node":
             return None
-        return GraphBucketWatch(self.opt, self.bucket_elems)
+        # finer buckets than the exchange behind the graph uses: a bucket is sendable when its LAST gradient exists, so a
+        # 64 MB bucket that reaches into the first encoder block waits for the end of the backward with all its bytes
+        mb = float(os.environ.get("COMA_DP_WATCH_BUCKET_MB", "16"))
+        return GraphBucketWatch(self.opt, max(1, min(self.bucket_elems, int(mb * (1 << 20)) // 4)))
 
     def reduce_flat_and_step(self, watch=None):
         """reduce_flat + optimizer.step(), pipelined: every bucket's all-reduce is queued up front (they run one after the

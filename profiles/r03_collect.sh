@@ -25,6 +25,10 @@ python profiles/side_stamps.py > $O/r03_side_stamps.txt 2>&1 || true
 tail -3 $O/r03_side_stamps.txt
 bash profiles/ab_env.sh "COMA_WGRAD_SIDE=0" "COMA_NO_DUO=1" "COMA_PREP_AHEAD=0" > $O/r03_ab_side_duo.txt 2>&1 || true
 cat $O/r03_ab_side_duo.txt
+echo "== graph-overlapped exchange: when are the gradient buckets sendable; what a stream outside the graph sees"
+GPU_MAX_HW_QUEUES=8 python profiles/dp_watch_timeline.py 128 --marks 2>&1 | grep -v amdgpu.ids > $O/r03_dp_watch_timeline.txt || true
+tail -7 $O/r03_dp_watch_timeline.txt
+(echo "# default hardware queues"; python profiles/external_event_probe.py 2>&1 | grep -v amdgpu.ids; echo "# GPU_MAX_HW_QUEUES=8"; GPU_MAX_HW_QUEUES=8 python profiles/external_event_probe.py 2>&1 | grep -v amdgpu.ids) > $O/r03_external_event_probe.txt || true
 echo "== microbenchmarks"
 python profiles/microbench_norm.py > $O/r03_microbench_norm.txt 2>&1 || true
 bash profiles/mb_tconv.sh > $O/r03_microbench_tconv.txt 2>&1 || true
