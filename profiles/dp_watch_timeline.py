@@ -56,7 +56,8 @@ if "--marks" in sys.argv:
         ps = [p for p in opt._flat_params if w._p2b[id(p)] == bi]
         seen = sorted((order[id(p)], names.get(id(p), "?")) for p in ps if id(p) in order)
         never = [names.get(id(p), "?") for p in ps if id(p) not in order]
-        print(f"bucket {bi}: {(e0 - s0) * 4 / 2 ** 20:.1f} MB, {len(ps)} parameters; first announced #{seen[0][0]} {seen[0][1]}; last three: {seen[-3:]}; never announced: {never[:6]}{' ...' if len(never) > 6 else ''} ({len(never)})")
+        first = f"first announced #{seen[0][0]} {seen[0][1]}; last three: {seen[-3:]}" if seen else "none announced"
+        print(f"bucket {bi}: {(e0 - s0) * 4 / 2 ** 20:.1f} MB, {len(ps)} parameters; {first}; never announced: {never[:6]}{' ...' if len(never) > 6 else ''} ({len(never)})")
 aux = torch.cuda.Stream()
 for it in range(4):
     t0 = torch.cuda.Event(enable_timing=True)
