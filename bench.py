@@ -409,7 +409,7 @@ def main():
             dp_info = {"mode": args.dp, "exchange_ms": round(float(tt[0]), 3), "local_step_ms": round(float(tt[1]), 3),
                        "exposed_ms": round(elapsed / args.steps * 1e3 - float(tt[1]), 3),
                        "gradient_mb": round(opt.flat_g.numel() * 4 / 2 ** 20, 1),
-                       "early_buckets": getattr(reducer, "early", None),
+                       "early_buckets": getattr(reducer, "early", None), "early_mb": getattr(reducer, "early_mb", None),
                        # torch mode under graph replay: were buckets sent from behind external events of the graph
                        # (data_parallel.GraphBucketWatch)?  "node" = yes; anything else = exchange behind the graph, and why
                        "graph_overlap": getattr(reducer, "watch_probe", None)}

@@ -197,6 +197,7 @@ class GradReducer:
                         works.append(dist.all_reduce(opt.flat_g[s0:e0], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                         done.add(i)
             self.early = len(done)
+            self.early_mb = round(sum(watch.bounds[i][1] - watch.bounds[i][0] for i in done) * 4 / 2 ** 20, 1)
             for i, (s0, e0) in enumerate(watch.bounds):
                 if i not in done:
                     spans.append((s0, e0 - s0))
@@ -383,6 +384,20 @@ class GraphBucketWatch:
             self._left[i] -= 1
             if self._left[i] == 0:
                 self._pending.append(i)
+
+    def spoil(self, p):
+        """A parameter whose slot was written through is used AGAIN in this step (a second pass through the model before the
+        backward: the triplet passes): autograd will add that gradient into the slot at a time nobody announces, so the
+        parameter's bucket is only complete when the backward is -- it goes behind the graph."""
+        i = self._p2b.get(id(p))
+        if i is None:
+            return
+        self._left[i] = 1 << 30
+        if i in self._pending:
+            self._pending.remove(i)
+        for todo, _evs in self.groups:
+            if i in todo:
+                todo.remove(i)
 
     def flush_pending(self):
         """Called at the next sink request: every kernel of the earlier requests has been enqueued on its stream."""

@@ -233,6 +233,8 @@ class GradSink:
         out = []
         for p in params:
             if p is None or not getattr(p, "_coma_sink", False) or p.grad is None or id(p) in cls.written:
+                if p is not None and cls.observer is not None and id(p) in cls.written:
+                    cls.observer.spoil(p)      # (a second use: autograd accumulates into the slot, unannounced)
                 out.append(None)
                 continue
             cls.written.add(id(p))

@@ -303,6 +303,47 @@ def test_grad_sink_multi_slot_node_does_not_flush_its_own_bucket_early():
         ops.GradSink.written.clear()
 
 
+def test_graph_bucket_watch_bookkeeping_and_second_use():
+    """data_parallel.GraphBucketWatch without a GPU: buckets cut at parameter boundaries, a bucket becomes pending when its
+    last write-through gradient has been announced, and a parameter that is used a SECOND time in the step (autograd will
+    accumulate into its slot unannounced) takes its bucket out of the early set -- also when it had already been flushed."""
+    from coma_unet_amd import ops
+    from coma_unet_amd.optim import FusedAdamW
+    from coma_unet_amd.data_parallel import GraphBucketWatch
+    ops.adamw_ = _cpu_adamw
+    torch.manual_seed(1)
+    net = _Net()
+    opt = FusedAdamW(net.parameters(), lr=1e-2, write_through=True)
+    net(torch.randn(4, 7)).sum().backward()
+    opt.step()                                              # builds the flat layout
+    w = GraphBucketWatch(opt, 16)                           # 16 elements per bucket: several buckets
+    assert len(w.bounds) > 2 and w.bounds[0][0] == 0 and w.bounds[-1][1] == opt.flat_g.numel()
+    assert all(a[1] == b[0] for a, b in zip(w.bounds, w.bounds[1:]))
+    starts = {opt._offsets[id(p)][0] for p in opt._flat_params}
+    assert all(s0 in starts for s0, _ in w.bounds), "buckets are cut at parameter boundaries"
+    w._left, w._pending, w.groups = list(w._total), [], []
+    ops.GradSink.written.clear()
+    ops.GradSink.observer = w
+    flushed = []
+    w.flush_pending = lambda: (flushed.append(list(w._pending)), w.groups.append((list(w._pending), [])), w._pending.clear()) if w._pending else None
+    try:
+        params = list(reversed(opt._flat_params))
+        for p in params:
+            assert ops.GradSink.slot(p) is p.grad
+        ops.GradSink.slot(None)
+        done = [i for g in flushed for i in g]
+        assert sorted(done) == [i for i in range(len(w.bounds)) if w._total[i] > 0], "every bucket of announced parameters completes once"
+        # a second use of one parameter: its bucket leaves the early set although it was flushed already
+        victim = params[0]
+        bi = w._p2b[id(victim)]
+        assert any(bi in todo for todo, _ in w.groups)
+        assert ops.GradSink.slot(victim) is None
+        assert not any(bi in todo for todo, _ in w.groups) and bi not in w._pending
+    finally:
+        ops.GradSink.observer = None
+        ops.GradSink.written.clear()
+
+
 def _worker_sharded_state(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

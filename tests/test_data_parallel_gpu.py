@@ -110,7 +110,7 @@ def _rank(rank, world, port, q, overlap):
         losses.append(float(step()[0][0].detach()))
     torch.cuda.synchronize()
     g = opt.flat_g.double()
-    sample = g[::4099].cpu()
+    sample = g[::4099].cpu().numpy()        # (by value: a torch tensor in the queue is a shared-memory handle the exiting rank takes with it)
     q.put((rank, overlap, red.watch_probe, getattr(red, "early", 0), losses, float(g.sum()), float(g.abs().sum()), sample))
     dist.barrier()
     dist.destroy_process_group()
@@ -124,6 +124,7 @@ def _run(overlap):
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    res = [t[:7] + (torch.from_numpy(t[7]),) for t in res]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
