@@ -28,11 +28,13 @@ import os
 import sys
 import time
 
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("COMA_BENCH_ONE_DEVICE") != "1":
     # N > 1: the exchange's streams (the auxiliary stream behind the graph's bucket events, the process group's own) should
     # not share a hardware queue with the replayed graph's streams, or their work is only SEEN when the graph's packets in
     # front of it have drained (profiles/external_event_probe.py).  The runtime's default is 4 queues; the one-GPU step is
     # insensitive to the setting (17.08 / 17.07 / 17.04 ms at 4 / 8 / 6).  Must be set before HIP initialises.
+    # One process per GPU only: TWO processes on one GPU (the gloo rehearsal) oversubscribe the device's hardware queues
+    # from 2 x 6 on and the scheduler then time-slices them (replayed step 13 -> 72 / 140 / 160 ms at 6 / 7 / 8).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
