@@ -9,7 +9,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-S = (32, 32, 32)
+S = (int(os.environ.get("COMA_TEST_DP_SIZE", "32")),) * 3      # (COMA_TEST_DP_SIZE=128: the same checks at the headline size)
 
 
 def _free_port():
